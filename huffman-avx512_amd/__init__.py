@@ -1,0 +1,267 @@
+"""MI355X-native K-stream Huffman codec: Python front end of libhfz.so.
+
+The codec itself is hand-written HIP behind a C ABI (include/hfz.h); this module
+only binds it with ctypes and mirrors the reference's compressor interface
+(codec/huffman.h:42-52: static Compress / Decompress / name).  There is no CPU
+fallback: if libhfz.so is missing or no GPU is usable, calls raise.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("huffman-avx512_amd")``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhfz.so")
+
+HFZ_OK = 0
+HFZ_E_ARG = -1
+HFZ_E_CAPACITY = -2
+HFZ_E_CORRUPT = -3
+HFZ_E_NO_DEVICE = -4
+HFZ_E_HIP = -5
+HFZ_E_TOO_LARGE = -6
+HFZ_E_WORKSPACE = -7
+MAX_STREAMS = 64
+
+# Every symbol include/hfz.h declares.
+EXPORTS = (
+    "hfz_version", "hfz_strerror", "hfz_last_hip_error", "hfz_device_count",
+    "hfz_compress_bound", "hfz_compress", "hfz_decompress", "hfz_decompressed_size",
+    "hfz_histogram", "hfz_build_code_table", "hfz_batch_frames", "hfz_workspace_bytes",
+    "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
+    "hfz_histogram_batch_dev", "hfz_generate_dev",
+)
+
+
+class HfzError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        detail = ""
+        try:
+            msg = lib().hfz_strerror(code).decode()
+            hip = lib().hfz_last_hip_error().decode()
+            detail = msg + (" [" + hip + "]" if hip and code in (HFZ_E_HIP, HFZ_E_NO_DEVICE) else "")
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__("%s failed: %d %s" % (where, code, detail))
+
+
+class CodeTable(ctypes.Structure):
+    _fields_ = [
+        ("bits", ctypes.c_uint16 * 256),
+        ("len", ctypes.c_uint8 * 256),
+        ("sorted_syms", ctypes.c_uint8 * 256),
+        ("len_count", ctypes.c_uint16 * 13),
+        ("num_syms", ctypes.c_uint16),
+        ("len_mask", ctypes.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libhfz.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhfz.so not built: run `make -C %s`" % os.path.join(_HERE, "csrc"))
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, ci, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
+        psz = ctypes.POINTER(ctypes.c_size_t)
+        L.hfz_version.restype = ctypes.c_char_p
+        L.hfz_strerror.restype = ctypes.c_char_p
+        L.hfz_strerror.argtypes = [ci]
+        L.hfz_last_hip_error.restype = ctypes.c_char_p
+        L.hfz_device_count.restype = ci
+        L.hfz_compress_bound.restype = sz
+        L.hfz_compress_bound.argtypes = [sz, ci]
+        L.hfz_compress.restype = ci
+        L.hfz_compress.argtypes = [ci, vp, sz, vp, sz, psz]
+        L.hfz_decompress.restype = ci
+        L.hfz_decompress.argtypes = [ci, vp, sz, vp, sz, psz]
+        L.hfz_decompressed_size.restype = ci
+        L.hfz_decompressed_size.argtypes = [vp, sz, psz]
+        L.hfz_histogram.restype = ci
+        L.hfz_histogram.argtypes = [vp, sz, vp]
+        L.hfz_build_code_table.restype = ci
+        L.hfz_build_code_table.argtypes = [vp, ctypes.POINTER(CodeTable)]
+        L.hfz_batch_frames.restype = sz
+        L.hfz_batch_frames.argtypes = [sz, sz]
+        L.hfz_workspace_bytes.restype = sz
+        L.hfz_workspace_bytes.argtypes = [ci, sz]
+        L.hfz_compress_batch_dev.restype = ci
+        L.hfz_compress_batch_dev.argtypes = [ci, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, sz, vp]
+        L.hfz_decompress_batch_dev.restype = ci
+        L.hfz_decompress_batch_dev.argtypes = [ci, vp, sz, vp, vp, sz, vp, sz, sz, vp, vp]
+        L.hfz_histogram_dev.restype = ci
+        L.hfz_histogram_dev.argtypes = [vp, sz, vp, vp]
+        L.hfz_histogram_batch_dev.restype = ci
+        L.hfz_histogram_batch_dev.argtypes = [vp, sz, sz, vp, vp]
+        L.hfz_generate_dev.restype = ci
+        L.hfz_generate_dev.argtypes = [vp, u64, u64, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc, where):
+    if rc != HFZ_OK:
+        raise HfzError(rc, where)
+
+
+def _host(b):
+    if isinstance(b, np.ndarray):
+        a = np.ascontiguousarray(b, dtype=np.uint8)
+    else:
+        a = np.frombuffer(bytes(b), dtype=np.uint8)
+    if a.size == 0:
+        return np.zeros(1, dtype=np.uint8), 0
+    return a, a.size
+
+
+# ---- host-buffer API (mirrors CompressMulti<K> / DecompressMulti<K>) -------
+
+def compress_bound(n, K):
+    return lib().hfz_compress_bound(n, K)
+
+
+def compress(K, raw):
+    """CompressMulti<K>(raw) (codec/huffman.h:9-10) on the GPU; returns bytes."""
+    a, n = _host(raw)
+    cap = compress_bound(n, K)
+    out = np.empty(cap, dtype=np.uint8)
+    got = ctypes.c_size_t()
+    _check(lib().hfz_compress(K, a.ctypes.data, n, out.ctypes.data, cap, ctypes.byref(got)),
+           "hfz_compress")
+    return out[: got.value].tobytes()
+
+
+def decompress(K, comp):
+    """DecompressMulti<K>(compressed) (codec/huffman.h:11-12) on the GPU."""
+    a, n = _host(comp)
+    raw = ctypes.c_size_t()
+    _check(lib().hfz_decompressed_size(a.ctypes.data, n, ctypes.byref(raw)), "hfz_decompressed_size")
+    out = np.empty(max(raw.value, 1), dtype=np.uint8)
+    got = ctypes.c_size_t()
+    _check(lib().hfz_decompress(K, a.ctypes.data, n, out.ctypes.data, raw.value, ctypes.byref(got)),
+           "hfz_decompress")
+    return out[: got.value].tobytes()
+
+
+def histogram(raw):
+    """MakeHistogram(str) (codec/histogram.h:12) on the GPU; 256 x uint32."""
+    a, n = _host(raw)
+    h = np.zeros(256, dtype=np.uint32)
+    _check(lib().hfz_histogram(a.ctypes.data, n, h.ctypes.data), "hfz_histogram")
+    return h
+
+
+def build_code_table(hist):
+    """MakeCanonicalCoding (codec/huffman.cpp:339-437); host only."""
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    if h.size != 256:
+        raise ValueError("histogram must have 256 bins")
+    t = CodeTable()
+    _check(lib().hfz_build_code_table(h.ctypes.data, ctypes.byref(t)), "hfz_build_code_table")
+    return t
+
+
+class HuffmanCompressorGpu:
+    """The reference's compressor concept (codec/huffman.h:42-52) for a fixed K."""
+
+    def __init__(self, K):
+        if not 1 <= K <= MAX_STREAMS:
+            raise ValueError("K must be in 1..%d" % MAX_STREAMS)
+        self.K = K
+
+    def Compress(self, raw):
+        return compress(self.K, raw)
+
+    def Decompress(self, compressed):
+        return decompress(self.K, compressed)
+
+    def name(self):
+        return "HuffmanGpu<%d>" % self.K
+
+
+# ---- device-resident batch API (torch tensors carry the device memory) -----
+
+class Batch:
+    """Compressed batch living in device memory."""
+
+    def __init__(self, K, comp, comp_off, comp_size, status, total, frame_bytes):
+        self.K, self.comp, self.comp_off, self.comp_size = K, comp, comp_off, comp_size
+        self.status, self.total, self.frame_bytes = status, total, frame_bytes
+
+    @property
+    def n_frames(self):
+        return int(self.comp_off.numel())
+
+    def frame_bytes_host(self, i):
+        off = int(self.comp_off[i].item())
+        size = int(self.comp_size[i].item())
+        return bytes(self.comp[off:off + size].cpu().numpy().tobytes())
+
+    def compressed_bytes(self):
+        return int(self.comp_size.to("cpu").to(dtype=__import__("torch").int64).sum().item())
+
+
+class BatchCodec:
+    """Pre-allocated buffers + the batch entry points for one (K, total, frame_bytes)."""
+
+    def __init__(self, K, total, frame_bytes, device="cuda", strided=False):
+        import torch
+        self.torch = torch
+        self.K, self.total, self.frame_bytes = K, total, frame_bytes
+        self.device = torch.device(device)
+        L = lib()
+        self.n_frames = L.hfz_batch_frames(total, frame_bytes)
+        bound = L.hfz_compress_bound(frame_bytes, K)
+        self.stride = ((bound + 255) // 256) * 256 if strided else 0
+        # packed capacity: the sum of per-frame bounds is a safe upper limit
+        self.comp_cap = self.n_frames * (self.stride if strided else bound)
+        self.comp = torch.empty(self.comp_cap, dtype=torch.uint8, device=self.device)
+        self.comp_off = torch.zeros(self.n_frames, dtype=torch.int64, device=self.device)
+        self.comp_size = torch.zeros(self.n_frames, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(self.n_frames, dtype=torch.int32, device=self.device)
+        self.dstatus = torch.zeros(self.n_frames, dtype=torch.int32, device=self.device)
+        self.ws_bytes = L.hfz_workspace_bytes(K, self.n_frames)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def compress(self, raw):
+        assert raw.dtype == self.torch.uint8 and raw.numel() == self.total and raw.is_cuda
+        _check(lib().hfz_compress_batch_dev(
+            self.K, raw.data_ptr(), self.total, self.frame_bytes, self.comp.data_ptr(),
+            self.comp_cap, self.stride, self.comp_off.data_ptr(), self.comp_size.data_ptr(),
+            self.status.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()),
+            "hfz_compress_batch_dev")
+        return Batch(self.K, self.comp, self.comp_off, self.comp_size, self.status, self.total,
+                     self.frame_bytes)
+
+    def decompress(self, batch, out=None):
+        torch = self.torch
+        if out is None:
+            out = torch.empty(max(self.total, 1), dtype=torch.uint8, device=self.device)
+        _check(lib().hfz_decompress_batch_dev(
+            self.K, batch.comp.data_ptr(), batch.comp.numel(), batch.comp_off.data_ptr(),
+            batch.comp_size.data_ptr(), batch.n_frames, out.data_ptr(), self.total,
+            self.frame_bytes, self.dstatus.data_ptr(), self._stream()),
+            "hfz_decompress_batch_dev")
+        return out[: self.total]
+
+
+def generate(cdf, seed, n, device="cuda", first_index=0):
+    """Synthetic bytes on the device (include/hfz.h: hfz_generate_dev)."""
+    import torch
+    c = torch.as_tensor(np.ascontiguousarray(cdf, dtype=np.uint32).view(np.int32)).to(device)
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device=device)
+    _check(lib().hfz_generate_dev(c.data_ptr(), seed, first_index, out.data_ptr(), n,
+                                  torch.cuda.current_stream().cuda_stream), "hfz_generate_dev")
+    torch.cuda.current_stream().synchronize()
+    return out[:n]

@@ -1,0 +1,370 @@
+// Host side of libhfz: canonical code construction, frame header bytes, the
+// C ABI entry points and HIP plumbing.  No compute happens here apart from the
+// 256-symbol table construction, which the reference also does once per frame
+// on the CPU (codec/huffman.cpp:339-437).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hfz_internal.h"
+
+namespace hfz {
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+int hip_fail(hipError_t e) {
+  g_last_hip_error = hipGetErrorString(e);
+  return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? HFZ_E_NO_DEVICE : HFZ_E_HIP;
+}
+#define HFZ_HIP(call)                            \
+  do {                                           \
+    hipError_t e__ = (hipError_t)(call);         \
+    if (e__ != hipSuccess) return hip_fail(e__); \
+  } while (0)
+
+bool have_device() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+// LimitCodeLengths, codec/huffman.cpp:297-327 (MiniZ method).  Lengths above
+// 12 are folded into 12, then codes are lengthened until the Kraft sum is 1.
+void limit_code_lengths(uint32_t* len_count, int max_seen) {
+  for (int i = kMaxCodeLen + 1; i <= max_seen; ++i) {
+    len_count[kMaxCodeLen] += len_count[i];
+    len_count[i] = 0;
+  }
+  uint32_t kraft = 0;
+  for (int i = 0; i <= kMaxCodeLen; ++i) kraft += len_count[i] << (kMaxCodeLen - i);
+  const uint32_t one = 1u << kMaxCodeLen;
+  while (kraft > one) {
+    --len_count[kMaxCodeLen];
+    for (int j = kMaxCodeLen - 1; j >= 0; --j) {
+      if (len_count[j] > 0) {
+        --len_count[j];
+        len_count[j + 1] += 2;
+        break;
+      }
+    }
+    --kraft;
+  }
+}
+
+}  // namespace
+
+// MakeCanonicalCoding, codec/huffman.cpp:339-437.  The symbol order comes from
+// the same std::sort call on the same initial sequence with the same
+// comparator as the reference (:342-354), so equal counts fall the same way.
+static void make_code_table(const uint32_t hist[256], hfz_code_table* t) {
+  std::memset(t, 0, sizeof(*t));
+  int n = 0;
+  for (int c = 0; c < 256; ++c)
+    if (hist[c] != 0) t->sorted_syms[n++] = (uint8_t)c;
+  t->num_syms = (uint16_t)n;
+  if (n == 0) return;
+  std::sort(t->sorted_syms, t->sorted_syms + n,
+            [&](uint8_t a, uint8_t b) { return hist[a] > hist[b]; });
+
+  // Two-queue Huffman construction (:364-416).  Queue 1: leaves, read from the
+  // low-count end of sorted_syms; queue 2: internal nodes in creation order.
+  // A leaf wins ties (:375).  Only depths are needed, so each node records its
+  // parent and depths are resolved from the root down afterwards.
+  uint32_t tree_count[256];
+  int leaf_parent[256], node_parent[256];
+  int next_sym = n - 1, next_node = 0, tree_size = 0;
+  auto pop = [&](int parent, uint32_t* count) {
+    bool leaf = false;
+    if (next_sym >= 0)
+      leaf = next_node == tree_size || hist[t->sorted_syms[next_sym]] <= tree_count[next_node];
+    if (leaf) {
+      *count = hist[t->sorted_syms[next_sym]];
+      leaf_parent[next_sym--] = parent;
+    } else {
+      *count = tree_count[next_node];
+      node_parent[next_node++] = parent;
+    }
+  };
+  while ((tree_size - next_node) + (next_sym + 1) > 1) {
+    uint32_t a, b;
+    pop(tree_size, &a);
+    pop(tree_size, &b);
+    tree_count[tree_size++] = a + b;
+  }
+  uint32_t len_count[256] = {};
+  int max_seen = 0;
+  if (tree_size == 0) {
+    len_count[0] = 1;  // a single symbol gets a zero-length code
+  } else {
+    int depth[256];
+    depth[tree_size - 1] = 0;  // the root is the last node created
+    for (int i = tree_size - 2; i >= 0; --i) depth[i] = depth[node_parent[i]] + 1;
+    for (int i = 0; i < n; ++i) {
+      int d = depth[leaf_parent[i]] + 1;
+      ++len_count[d];
+      max_seen = std::max(max_seen, d);
+    }
+  }
+  limit_code_lengths(len_count, max_seen);
+
+  uint32_t cur = 0, inc = 1u << kMaxCodeLen;  // ForallCodes, :260-284
+  int i = 0;
+  for (int len = 0; len <= kMaxCodeLen; ++len) {
+    t->len_count[len] = (uint16_t)len_count[len];
+    if (len_count[len]) t->len_mask |= 1u << len;
+    for (uint32_t j = 0; j < len_count[len]; ++j) {
+      const uint8_t s = t->sorted_syms[i++];
+      t->bits[s] = (uint16_t)cur;
+      t->len[s] = (uint8_t)len;
+      cur += inc;
+    }
+    inc >>= 1;
+  }
+}
+
+void build_frame_code(const uint32_t hist[256], FrameCode* out) {
+  hfz_code_table t;
+  make_code_table(hist, &t);
+  for (int c = 0; c < 256; ++c) out->enc[c] = (uint16_t)((t.bits[c] << 4) | t.len[c]);
+  // header bytes after raw_size: len_mask, counts (256 -> 0x00), symbols (:800-808)
+  uint8_t* p = out->hdr;
+  std::memcpy(p, &t.len_mask, 4);
+  p += 4;
+  for (int len = 0; len <= kMaxCodeLen; ++len)
+    if (t.len_count[len]) *p++ = (uint8_t)t.len_count[len];
+  std::memcpy(p, t.sorted_syms, t.num_syms);
+  p += t.num_syms;
+  out->hdr_len = (uint32_t)(p - out->hdr);
+  std::memset(p, 0, sizeof(out->hdr) - out->hdr_len);
+}
+
+}  // namespace hfz
+
+using namespace hfz;
+
+extern "C" {
+
+const char* hfz_version(void) { return "hfz 0.1 (gfx950)"; }
+
+const char* hfz_strerror(int code) {
+  switch (code) {
+    case HFZ_OK: return "ok";
+    case HFZ_E_ARG: return "bad argument";
+    case HFZ_E_CAPACITY: return "destination too small";
+    case HFZ_E_CORRUPT: return "corrupt frame";
+    case HFZ_E_NO_DEVICE: return "no HIP device";
+    case HFZ_E_HIP: return "HIP call failed";
+    case HFZ_E_TOO_LARGE: return "frame too large";
+    case HFZ_E_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+const char* hfz_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int hfz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+size_t hfz_compress_bound(size_t n, int K) {
+  if (K < 1) K = 1;
+  return 8 + 13 + 256 + 4 * (size_t)(K - 1) + (n * 12 + 7) / 8 + 9 * (size_t)K;
+}
+
+int hfz_build_code_table(const uint32_t hist[256], hfz_code_table* out) {
+  if (!hist || !out) return HFZ_E_ARG;
+  make_code_table(hist, out);
+  return HFZ_OK;
+}
+
+size_t hfz_batch_frames(size_t total, size_t frame_bytes) {
+  if (frame_bytes == 0) return 0;
+  if (total == 0) return 1;
+  return (total + frame_bytes - 1) / frame_bytes;
+}
+
+size_t hfz_workspace_bytes(int K, size_t n_frames) {
+  (void)K;
+  return workspace_layout(n_frames).total;
+}
+
+int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes, uint32_t* d_hist,
+                            void* stream) {
+  if (!d_hist || frame_bytes == 0 || (total && !d_raw)) return HFZ_E_ARG;
+  if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  const size_t nf = hfz_batch_frames(total, frame_bytes);
+  HFZ_HIP(launch_histogram((const uint8_t*)d_raw, total, frame_bytes, nf, d_hist, stream));
+  return HFZ_OK;
+}
+
+int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream) {
+  if (!d_hist || (n && !d_src)) return HFZ_E_ARG;
+  // one "frame" covering everything; counts wrap at 2^32 like the u32 bins of
+  // ByteHistogram (codec/histogram.h:10)
+  HFZ_HIP(launch_histogram((const uint8_t*)d_src, n, n ? n : 1, 1, d_hist, stream));
+  return HFZ_OK;
+}
+
+int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                           void* d_comp, size_t comp_cap, size_t comp_stride,
+                           uint64_t* d_comp_off, uint32_t* d_comp_size, int32_t* d_status,
+                           void* d_ws, size_t ws_bytes, void* stream) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || frame_bytes == 0 || !d_comp || !d_comp_off ||
+      !d_comp_size || !d_ws || (total && !d_raw))
+    return HFZ_E_ARG;
+  if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  if (comp_stride && comp_stride < hfz_compress_bound(frame_bytes, K)) return HFZ_E_ARG;
+  const size_t nf = hfz_batch_frames(total, frame_bytes);
+  const WorkspaceLayout w = workspace_layout(nf);
+  if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
+  uint8_t* ws = (uint8_t*)d_ws;
+  uint32_t* d_hist = (uint32_t*)(ws + w.hist);
+  FrameCode* d_code = (FrameCode*)(ws + w.code);
+  uint32_t* d_send = (uint32_t*)(ws + w.stream_end);
+  uint32_t* d_csize = (uint32_t*)(ws + w.csize);
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* raw = (const uint8_t*)d_raw;
+
+  HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+  // canonical codes on the host, one per frame
+  {
+    std::vector<uint32_t> hist(nf * 256);
+    std::vector<FrameCode> code(nf);
+    HFZ_HIP(hipMemcpyAsync(hist.data(), d_hist, nf * 256 * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HFZ_HIP(hipStreamSynchronize(st));
+    for (size_t f = 0; f < nf; ++f) build_frame_code(&hist[f * 256], &code[f]);
+    HFZ_HIP(hipMemcpyAsync(d_code, code.data(), nf * sizeof(FrameCode), hipMemcpyHostToDevice, st));
+    HFZ_HIP(hipStreamSynchronize(st));
+  }
+  HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_code, d_send, d_csize, stream));
+  HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
+                               d_status, stream));
+  HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, d_code, d_send, d_comp_off, d_comp_size,
+                        (uint8_t*)d_comp, comp_cap, stream));
+  return HFZ_OK;
+}
+
+int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
+                             const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                             size_t n_frames, void* d_raw, size_t raw_cap, size_t frame_bytes,
+                             int32_t* d_status, void* stream) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || !d_comp || !d_comp_off || !d_comp_size || frame_bytes == 0 ||
+      (raw_cap && !d_raw))
+    return HFZ_E_ARG;
+  if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  HFZ_HIP(launch_decode(K, (const uint8_t*)d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames,
+                        (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
+  return HFZ_OK;
+}
+
+int hfz_generate_dev(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, void* d_out,
+                     size_t n, void* stream) {
+  if (!d_cdf || (n && !d_out)) return HFZ_E_ARG;
+  HFZ_HIP(launch_generate(d_cdf, seed, first_index, (uint8_t*)d_out, n, stream));
+  return HFZ_OK;
+}
+
+// ---- host-buffer single-frame entry points --------------------------------
+
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+}  // namespace
+
+int hfz_histogram(const void* src, size_t n, uint32_t hist[256]) {
+  if (!hist || (n && !src)) return HFZ_E_ARG;
+  if (!have_device()) return HFZ_E_NO_DEVICE;
+  DevBuf d_src, d_hist;
+  HFZ_HIP(d_src.alloc(n));
+  HFZ_HIP(d_hist.alloc(256 * sizeof(uint32_t)));
+  if (n) HFZ_HIP(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+  int rc = hfz_histogram_dev(d_src.p, n, (uint32_t*)d_hist.p, nullptr);
+  if (rc != HFZ_OK) return rc;
+  HFZ_HIP(hipMemcpy(hist, d_hist.p, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return HFZ_OK;
+}
+
+int hfz_compress(int K, const void* src, size_t n, void* dst, size_t cap, size_t* out_n) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || !dst || !out_n || (n && !src)) return HFZ_E_ARG;
+  if (n > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  if (!have_device()) return HFZ_E_NO_DEVICE;
+  const size_t bound = hfz_compress_bound(n, K);
+  const size_t ws_bytes = hfz_workspace_bytes(K, 1);
+  DevBuf d_raw, d_comp, d_ws, d_meta;
+  HFZ_HIP(d_raw.alloc(n));
+  HFZ_HIP(d_comp.alloc(bound));
+  HFZ_HIP(d_ws.alloc(ws_bytes));
+  HFZ_HIP(d_meta.alloc(32));
+  if (n) HFZ_HIP(hipMemcpy(d_raw.p, src, n, hipMemcpyHostToDevice));
+  uint64_t* d_off = (uint64_t*)d_meta.p;
+  uint32_t* d_size = (uint32_t*)((uint8_t*)d_meta.p + 8);
+  int32_t* d_status = (int32_t*)((uint8_t*)d_meta.p + 16);
+  int rc = hfz_compress_batch_dev(K, d_raw.p, n, n ? n : 1, d_comp.p, bound, 0, d_off, d_size,
+                                  d_status, d_ws.p, ws_bytes, nullptr);
+  if (rc != HFZ_OK) return rc;
+  uint8_t meta[32];
+  HFZ_HIP(hipMemcpy(meta, d_meta.p, 32, hipMemcpyDeviceToHost));
+  uint32_t size;
+  int32_t status;
+  std::memcpy(&size, meta + 8, 4);
+  std::memcpy(&status, meta + 16, 4);
+  if (status != HFZ_OK) return status;
+  *out_n = size;
+  if (size > cap) return HFZ_E_CAPACITY;
+  HFZ_HIP(hipMemcpy(dst, d_comp.p, size, hipMemcpyDeviceToHost));
+  return HFZ_OK;
+}
+
+int hfz_decompressed_size(const void* src, size_t n, size_t* raw_size) {
+  if (!src || !raw_size) return HFZ_E_ARG;
+  if (n < 8) return HFZ_E_CORRUPT;
+  uint32_t v;
+  std::memcpy(&v, src, 4);
+  *raw_size = v;
+  return HFZ_OK;
+}
+
+int hfz_decompress(int K, const void* src, size_t n, void* dst, size_t cap, size_t* out_n) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || !src || !out_n || (cap && !dst)) return HFZ_E_ARG;
+  size_t raw_size = 0;
+  int rc = hfz_decompressed_size(src, n, &raw_size);
+  if (rc != HFZ_OK) return rc;
+  *out_n = raw_size;
+  if (raw_size > cap) return HFZ_E_CAPACITY;
+  if (raw_size > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  if (!have_device()) return HFZ_E_NO_DEVICE;
+  DevBuf d_comp, d_raw, d_meta;
+  HFZ_HIP(d_comp.alloc(n));
+  HFZ_HIP(d_raw.alloc(raw_size));
+  HFZ_HIP(d_meta.alloc(32));
+  HFZ_HIP(hipMemcpy(d_comp.p, src, n, hipMemcpyHostToDevice));
+  uint8_t meta[32] = {};
+  const uint32_t size32 = (uint32_t)n;
+  if (n > 0xffffffffull) return HFZ_E_TOO_LARGE;
+  std::memcpy(meta + 8, &size32, 4);
+  HFZ_HIP(hipMemcpy(d_meta.p, meta, 32, hipMemcpyHostToDevice));
+  rc = hfz_decompress_batch_dev(K, d_comp.p, n, (const uint64_t*)d_meta.p,
+                                (const uint32_t*)((uint8_t*)d_meta.p + 8), 1, d_raw.p, raw_size,
+                                raw_size ? raw_size : 1, (int32_t*)((uint8_t*)d_meta.p + 16),
+                                nullptr);
+  if (rc != HFZ_OK) return rc;
+  HFZ_HIP(hipMemcpy(meta, d_meta.p, 32, hipMemcpyDeviceToHost));
+  int32_t status;
+  std::memcpy(&status, meta + 16, 4);
+  if (status != HFZ_OK) return status;
+  if (raw_size) HFZ_HIP(hipMemcpy(dst, d_raw.p, raw_size, hipMemcpyDeviceToHost));
+  return HFZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Shared between the host side (hfz_host.cpp) and the kernels (hfz_kernels.hip).
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/hfz.h"
+
+namespace hfz {
+
+constexpr int kMaxCodeLen = 12;  // codec/huffman.cpp:38
+constexpr int kSlop = 8;         // codec/huffman.cpp:770
+
+// Everything a frame needs besides its raw bytes, one record per frame in the
+// workspace.  `enc[c]` = (code << 4) | len with the code left-aligned in 12
+// bits (the packing of the reference's permute encoder,
+// codec/huffman.cpp:1095-1111).  `hdr` holds header bytes 4.. of the frame
+// (len_mask, per-length counts, canonical symbol order; codec/huffman.cpp:800-808).
+struct FrameCode {
+  uint16_t enc[256];
+  uint8_t hdr[276];
+  uint32_t hdr_len;
+};
+static_assert(sizeof(FrameCode) == 512 + 276 + 4, "FrameCode layout");
+
+// Workspace carve-up for n frames (all offsets 256-byte aligned).
+struct WorkspaceLayout {
+  size_t hist;        // u32 [n][256]
+  size_t code;        // FrameCode [n]
+  size_t stream_end;  // u32 [n][64]  cumulative stream end offsets (incl. slop)
+  size_t csize;       // u32 [n]      frame sizes
+  size_t total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline WorkspaceLayout workspace_layout(size_t n) {
+  WorkspaceLayout w;
+  size_t off = 0;
+  w.hist = off;
+  off = align256(off + n * 256 * sizeof(uint32_t));
+  w.code = off;
+  off = align256(off + n * sizeof(FrameCode));
+  w.stream_end = off;
+  off = align256(off + n * 64 * sizeof(uint32_t));
+  w.csize = off;
+  off = align256(off + n * sizeof(uint32_t));
+  w.total = off;
+  return w;
+}
+
+// Host-side canonical code construction (hfz_host.cpp).
+void build_frame_code(const uint32_t hist[256], FrameCode* out);
+
+// Kernel launchers (hfz_kernels.hip).  All return a hipError_t as int.
+int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                     uint64_t n_frames, uint32_t* d_hist, void* stream);
+int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                        uint64_t n_frames, const FrameCode* d_code, uint32_t* d_stream_end,
+                        uint32_t* d_csize, void* stream);
+int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
+                         uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                         int32_t* d_status, void* stream);
+int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                  uint64_t n_frames, const FrameCode* d_code, const uint32_t* d_stream_end,
+                  const uint64_t* d_comp_off, const uint32_t* d_comp_size, uint8_t* d_comp,
+                  uint64_t comp_cap, void* stream);
+int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
+                  const uint32_t* d_comp_size, uint64_t n_frames, uint8_t* d_raw,
+                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream);
+int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, uint8_t* d_out,
+                    uint64_t n, void* stream);
+
+}  // namespace hfz

@@ -1,0 +1,556 @@
+// gfx950 kernels of the K-stream Huffman codec: byte histogram, per-stream
+// coded size, frame placement, encode, decode-table build + decode, and the
+// synthetic data source.  One wavefront (64 lanes) owns one frame and one lane
+// owns one stream of it.
+#include <hip/hip_runtime.h>
+
+#include "hfz_internal.h"
+
+namespace hfz {
+namespace {
+
+typedef uint32_t __attribute__((aligned(1))) u32_u;
+typedef uint64_t __attribute__((aligned(1))) u64_u;
+
+__device__ __forceinline__ uint32_t load_u32u(const uint8_t* p) { return *(const u32_u*)p; }
+__device__ __forceinline__ uint64_t load_u64u(const uint8_t* p) { return *(const u64_u*)p; }
+__device__ __forceinline__ void store_u32u(uint8_t* p, uint32_t v) { *(u32_u*)p = v; }
+
+// SliceSizes<K> (codec/huffman.cpp:98-108) in closed form: slice k of n bytes.
+struct Slice {
+  uint32_t begin, size;
+};
+__device__ __forceinline__ Slice slice_of(uint32_t n, uint32_t K, uint32_t k) {
+  const uint32_t q = n / K, r = n % K;
+  Slice s;
+  s.begin = k * q + (k < r ? k : r);
+  s.size = q + (k < r ? 1u : 0u);
+  return s;
+}
+
+__device__ __forceinline__ uint32_t frame_len(uint64_t total, uint64_t frame_bytes, uint64_t f) {
+  const uint64_t fb = f * frame_bytes;
+  const uint64_t left = total > fb ? total - fb : 0;
+  return (uint32_t)(left < frame_bytes ? left : frame_bytes);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= (uint32_t)d) v += o;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// K1: byte histogram (codec/histogram.cpp:193-201 computes the same counts).
+// 8 interleaved sub-histograms per block (bin*8 + (lane&7)) keep equal bytes
+// in neighbouring lanes off one LDS address; the reference spreads its counts
+// over 8 arrays for the same reason (codec/histogram.cpp:18).
+__global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ raw,
+                                                   uint64_t total, uint64_t frame_bytes,
+                                                   uint32_t bpf, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256 * 8];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t f = blockIdx.x / bpf;
+  const uint32_t b = blockIdx.x % bpf;
+  for (uint32_t i = tid; i < 2048; i += 256) h[i] = 0;
+  __syncthreads();
+
+  const uint64_t n = frame_len(total, frame_bytes, f);
+  const uint64_t piece = ((n + bpf - 1) / bpf + 15) & ~uint64_t(15);
+  const uint64_t lo = (uint64_t)b * piece < n ? (uint64_t)b * piece : n;
+  const uint64_t hi = lo + piece < n ? lo + piece : n;
+  const uint8_t* s = raw + f * frame_bytes + lo;
+  const uint8_t* e = raw + f * frame_bytes + hi;
+  const uint8_t* a0 = (const uint8_t*)(((uintptr_t)s + 15) & ~uintptr_t(15));
+  const uint8_t* a1 = (const uint8_t*)((uintptr_t)e & ~uintptr_t(15));
+  const uint32_t rep = tid & 7;
+  if (a0 >= a1) {
+    for (const uint8_t* q = s + tid; q < e; q += 256) atomicAdd(&h[(uint32_t)*q * 8 + rep], 1u);
+  } else {
+    for (const uint8_t* q = s + tid; q < a0; q += 256) atomicAdd(&h[(uint32_t)*q * 8 + rep], 1u);
+    for (const uint8_t* q = a1 + tid; q < e; q += 256) atomicAdd(&h[(uint32_t)*q * 8 + rep], 1u);
+    for (const uint8_t* q = a0 + (size_t)tid * 16; q < a1; q += 256 * 16) {
+      const uint4 v = *(const uint4*)q;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          atomicAdd(&h[((w[j] >> (8 * k)) & 0xff) * 8 + rep], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t sum = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) sum += h[tid * 8 + r];
+  if (bpf == 1)
+    hist[f * 256 + tid] = sum;
+  else if (sum)
+    atomicAdd(&hist[f * 256 + tid], sum);
+}
+
+// ---------------------------------------------------------------------------
+// K2: coded size of every stream of a frame (codec/huffman.cpp:770-786):
+// size_k = ceil(sum of code lengths over slice k / 8) + 8, then prefix sums.
+__device__ __forceinline__ uint32_t sum_code_len(const uint8_t* p, uint32_t n,
+                                                 const uint8_t* lens) {
+  uint32_t bits = 0, i = 0;
+  while (i < n && ((uintptr_t)(p + i) & 15)) bits += lens[p[i++]];
+  for (; i + 16 <= n; i += 16) {
+    const uint4 v = *(const uint4*)(p + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bits += lens[(w[j] >> (8 * k)) & 0xff];
+    }
+  }
+  for (; i < n; ++i) bits += lens[p[i]];
+  return bits;
+}
+
+__global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __restrict__ raw,
+                                                   uint64_t total, uint64_t frame_bytes,
+                                                   const FrameCode* __restrict__ code,
+                                                   uint32_t* __restrict__ stream_end,
+                                                   uint32_t* __restrict__ csize) {
+  __shared__ uint8_t lens[256];
+  const uint64_t f = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const FrameCode& fc = code[f];
+  for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(fc.enc[i] & 15);
+  __syncthreads();
+  const uint32_t n = frame_len(total, frame_bytes, f);
+  uint32_t bytes = 0;
+  if (lane < K) {
+    const Slice s = slice_of(n, K, lane);
+    const uint32_t bits = sum_code_len(raw + f * frame_bytes + s.begin, s.size, lens);
+    bytes = (bits + 7) / 8 + kSlop;
+  }
+  const uint32_t incl = wave_inclusive_scan(bytes, lane);
+  if (lane < K) stream_end[f * 64 + lane] = incl;
+  if (lane == K - 1) csize[f] = 4 + fc.hdr_len + 4 * (K - 1) + incl;
+}
+
+// ---------------------------------------------------------------------------
+// Frame placement: exclusive prefix sum of the frame sizes (packed layout) or
+// i*stride (slot layout).  One block; frames are few compared with bytes.
+__global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t* __restrict__ csize,
+                                                       uint64_t n_frames, uint64_t stride,
+                                                       uint64_t cap,
+                                                       uint64_t* __restrict__ comp_off,
+                                                       uint32_t* __restrict__ comp_size,
+                                                       int32_t* __restrict__ status) {
+  __shared__ uint64_t wave_tot[16];
+  __shared__ uint64_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n_frames; base += 1024) {
+    const uint64_t i = base + tid;
+    const uint64_t v = i < n_frames ? csize[i] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t o = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint64_t before = carry_s;
+    for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
+    if (i < n_frames) {
+      const uint64_t off = stride ? i * stride : before + incl - v;
+      const bool ok = off <= cap && v <= cap - off && (stride == 0 || v <= stride);
+      comp_off[i] = off;
+      comp_size[i] = (uint32_t)v;
+      if (status) status[i] = ok ? HFZ_OK : HFZ_E_CAPACITY;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: encode.  Lane k packs slice k MSB-first into a 64-bit accumulator and
+// stores finished 32-bit pieces towards lower addresses, which yields the
+// bytes CodeWriter (codec/huffman.cpp:439-500) leaves behind: bit i of the
+// stream is bit 7-(i&7) of byte end-1-(i>>3); the 8 bytes at the start of the
+// stream region stay zero.
+__global__ __launch_bounds__(64) void encode_kernel(
+    uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
+    const FrameCode* __restrict__ code, const uint32_t* __restrict__ stream_end,
+    const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
+    uint8_t* __restrict__ comp, uint64_t cap) {
+  __shared__ uint16_t enc[256];
+  const uint64_t f = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const FrameCode& fc = code[f];
+  for (uint32_t i = lane; i < 256; i += 64) enc[i] = fc.enc[i];
+  __syncthreads();
+
+  const uint64_t off = comp_off[f];
+  const uint32_t size = comp_size[f];
+  if (off > cap || size > cap - off) return;  // reported by offsets_kernel
+  uint8_t* out = comp + off;
+  const uint32_t n = frame_len(total, frame_bytes, f);
+  const uint32_t hdr_len = fc.hdr_len;
+  const uint32_t hdr_total = 4 + hdr_len + 4 * (K - 1);
+
+  // header: raw_size | len_mask | counts | sorted symbols | K-1 end offsets
+  if (lane < 4) out[lane] = (uint8_t)(n >> (8 * lane));
+  for (uint32_t i = lane; i < hdr_len; i += 64) out[4 + i] = fc.hdr[i];
+  if (lane < K - 1) store_u32u(out + 4 + hdr_len + 4 * lane, stream_end[f * 64 + lane]);
+
+  if (lane >= K) return;
+  const uint32_t end = stream_end[f * 64 + lane];
+  const uint32_t begin = lane ? stream_end[f * 64 + lane - 1] : 0;
+  uint8_t* rb = out + hdr_total + begin;
+  uint8_t* pos = out + hdr_total + end;
+  store_u32u(rb, 0);
+  store_u32u(rb + 4, 0);
+
+  const Slice s = slice_of(n, K, lane);
+  const uint8_t* p = raw + f * frame_bytes + s.begin;
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+#define HFZ_PUT(byte)                                  \
+  do {                                                 \
+    const uint32_t e_ = enc[(byte)];                   \
+    acc |= (uint64_t)(e_ >> 4) << (52 - nb);           \
+    nb += e_ & 15;                                     \
+    if (nb >= 32) {                                    \
+      pos -= 4;                                        \
+      store_u32u(pos, (uint32_t)(acc >> 32));          \
+      acc <<= 32;                                      \
+      nb -= 32;                                        \
+    }                                                  \
+  } while (0)
+  uint32_t i = 0;
+  const uint32_t cnt = s.size;
+  while (i < cnt && ((uintptr_t)(p + i) & 15)) HFZ_PUT(p[i++]);
+  for (; i + 16 <= cnt; i += 16) {
+    const uint4 v = *(const uint4*)(p + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) HFZ_PUT((w[j] >> (8 * k)) & 0xff);
+    }
+  }
+  for (; i < cnt; ++i) HFZ_PUT(p[i]);
+#undef HFZ_PUT
+  while (nb > 0) {
+    *--pos = (uint8_t)(acc >> 56);
+    acc <<= 8;
+    nb = nb > 8 ? nb - 8 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4 + K5: decode.  The 4096-entry two-symbol table of Decoder2x
+// (codec/huffman.cpp:644-681) is rebuilt in LDS from the frame header, then
+// lane k decodes stream k (CodeReader + Decode, codec/huffman.cpp:502-586,
+// 683-689, 931-953).  Entry layout (u32): bits 0-7 bits consumed,
+// 8-15 first symbol, 16-23 second symbol (0 if none), 24-25 symbol count,
+// 28-31 length of the first code.
+__global__ __launch_bounds__(64) void decode_kernel(
+    uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
+    const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
+    uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
+    int32_t* __restrict__ status) {
+  __shared__ uint32_t tab[4096];
+  __shared__ uint8_t syms[256];
+  const uint64_t f = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+
+  const uint64_t off = comp_off[f];
+  const uint32_t size = comp_size[f];
+  int err = HFZ_OK;
+  if (off > comp_bytes || size > comp_bytes - off || size < 8) {
+    if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
+    return;
+  }
+  const uint8_t* in = comp + off;
+  const uint32_t raw_size = load_u32u(in);
+  const uint32_t len_mask = load_u32u(in + 4);
+  const uint64_t out_base = f * frame_bytes;
+  uint64_t room = out_base <= raw_cap ? raw_cap - out_base : 0;
+  if (room > frame_bytes) room = frame_bytes;
+  if (raw_size > room) err = HFZ_E_CAPACITY;
+  const uint32_t nlen = __popc(len_mask);
+  if ((len_mask >> (kMaxCodeLen + 1)) != 0 || 8 + nlen > size) err = HFZ_E_CORRUPT;
+  if (err != HFZ_OK) {
+    if (lane == 0 && status) status[f] = err;
+    return;
+  }
+
+  // ParseCompressedHeader (codec/huffman.cpp:714-736) + canonical code starts
+  // (ForallCodes, codec/huffman.cpp:260-284).
+  uint32_t cnt[kMaxCodeLen + 1], fcode[kMaxCodeLen + 2], soff[kMaxCodeLen + 1];
+  uint32_t cur = 0, nsym = 0, hp = 8;
+#pragma unroll
+  for (int L = 0; L <= kMaxCodeLen; ++L) {
+    uint32_t c = 0;
+    if ((len_mask >> L) & 1) {
+      c = in[hp++];
+      if (c == 0 && nlen == 1) c = 256;  // 256 is stored as 0 (:724-728)
+    }
+    cnt[L] = c;
+    fcode[L] = cur;
+    soff[L] = nsym;
+    cur += c << (kMaxCodeLen - L);
+    nsym += c;
+  }
+  fcode[kMaxCodeLen + 1] = cur;
+  const uint32_t hdr_total = 8 + nlen + nsym + 4 * (K - 1);
+  if (nsym > 256 || (uint64_t)hdr_total + (uint64_t)kSlop * K > size) err = HFZ_E_CORRUPT;
+  if (nsym == 0 ? raw_size != 0 : cur != (1u << kMaxCodeLen)) err = HFZ_E_CORRUPT;
+  if (err != HFZ_OK) {
+    if (lane == 0 && status) status[f] = err;
+    return;
+  }
+
+  for (uint32_t i = lane; i < nsym; i += 64) syms[i] = in[8 + nlen + i];
+  __syncthreads();
+  // single-symbol entries, one code-length class at a time
+#pragma unroll
+  for (int L = 0; L <= kMaxCodeLen; ++L) {
+    if (cnt[L] == 0) continue;
+    const uint32_t lo = fcode[L], hi = fcode[L + 1];
+    for (uint32_t e = lo + lane; e < hi; e += 64) {
+      const uint32_t j = soff[L] + ((e - lo) >> (kMaxCodeLen - L));
+      tab[e] = (uint32_t)L | ((uint32_t)syms[j] << 8) | (1u << 24) | ((uint32_t)L << 28);
+    }
+  }
+  __syncthreads();
+  // second symbol where both codes fit in 12 bits.  Bits 8-15 and 28-31 of an
+  // entry never change, so reading another lane's entry mid-update is safe.
+  for (uint32_t e = lane; e < 4096; e += 64) {
+    const uint32_t t = tab[e];
+    const uint32_t L1 = t >> 28;
+    const uint32_t t2 = tab[(e << L1) & 0xfff];
+    const uint32_t L2 = t2 >> 28;
+    if (L1 + L2 <= (uint32_t)kMaxCodeLen)
+      tab[e] = (L1 + L2) | (t & 0xff00) | ((t2 & 0xff00) << 8) | (2u << 24) | (L1 << 28);
+  }
+  __syncthreads();
+
+  // stream boundaries (codec/huffman.cpp:897-901)
+  const uint8_t* area = in + hdr_total;
+  const uint32_t area_size = size - hdr_total;
+  uint32_t end = 0, begin = 0;
+  bool bad = false;
+  if (lane < K) {
+    const uint8_t* eo = in + 8 + nlen + nsym;
+    end = lane < K - 1 ? load_u32u(eo + 4 * lane) : area_size;
+    begin = lane ? load_u32u(eo + 4 * (lane - 1)) : 0;
+    bad = end > area_size || begin > end || end - begin < (uint32_t)kSlop;
+  }
+  if (__any(bad)) {
+    if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
+    return;
+  }
+  if (lane == 0 && status) status[f] = HFZ_OK;
+  if (lane >= K) return;
+
+  const Slice s = slice_of(raw_size, K, lane);
+  uint8_t* out = raw + out_base + s.begin;
+  uint32_t remaining = s.size;  // symbols still to decode
+  int64_t ip = (int64_t)end - 8;  // window start, relative to `area`
+  uint32_t used = 0;
+  uint64_t obuf = 0;
+  uint32_t ocnt = 0;
+
+#define HFZ_LOOKUP(win)                                              \
+  do {                                                               \
+    const uint32_t e_ = tab[(uint32_t)(((win) << used) >> 52)];      \
+    obuf |= (uint64_t)((e_ >> 8) & 0xffff) << (8 * ocnt);            \
+    ocnt += (e_ >> 24) & 3;                                          \
+    used += e_ & 0xff;                                               \
+  } while (0)
+#define HFZ_DRAIN()                      \
+  do {                                   \
+    if (ocnt >= 4) {                     \
+      store_u32u(out, (uint32_t)obuf);   \
+      out += 4;                          \
+      obuf >>= 32;                       \
+      ocnt -= 4;                         \
+    }                                    \
+  } while (0)
+
+  // fast loop: two lookups (<= 4 symbols, <= 24 bits) per 8-byte window
+  while (remaining >= 4) {
+    ip -= used >> 3;
+    used &= 7;
+    if (ip < 0) break;
+    const uint64_t win = load_u64u(area + ip);
+    const uint32_t before = ocnt;
+    HFZ_LOOKUP(win);
+    HFZ_LOOKUP(win);
+    remaining -= ocnt - before;
+    HFZ_DRAIN();
+  }
+  // tail: one lookup at a time, window zero-extended below the stream area
+  // (FillBuffer, codec/huffman.cpp:536-556)
+  while (remaining > 0) {
+    ip -= used >> 3;
+    used &= 7;
+    uint64_t win = 0;
+    if (ip >= 0) {
+      win = load_u64u(area + ip);
+    } else if (ip > -8) {
+      win = load_u64u(area) << (8 * (uint32_t)(-ip));
+    }
+    const uint32_t e = tab[(uint32_t)((win << used) >> 52)];
+    uint32_t ns = (e >> 24) & 3;
+    uint32_t pair = (e >> 8) & 0xffff;
+    if (ns > remaining) {  // last symbol of the slice: Decode1 (:875-878)
+      ns = 1;
+      pair &= 0xff;
+    }
+    obuf |= (uint64_t)pair << (8 * ocnt);
+    ocnt += ns;
+    used += e & 0xff;
+    remaining -= ns;
+    HFZ_DRAIN();
+  }
+  while (ocnt > 0) {
+    *out++ = (uint8_t)obuf;
+    obuf >>= 8;
+    --ocnt;
+  }
+#undef HFZ_LOOKUP
+#undef HFZ_DRAIN
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic source: inverse-CDF sampling of a 256-symbol distribution from a
+// counter-based splitmix64 stream; integer arithmetic only.
+__device__ __forceinline__ uint32_t sample_byte(const uint32_t* cdf, uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const uint32_t u = (uint32_t)(z >> 32);
+  uint32_t lo = 0, hi = 255;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const bool right = lo < hi && cdf[mid] <= u;
+    const bool left = lo < hi && !right;
+    lo = right ? mid + 1 : lo;
+    hi = left ? mid : hi;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void generate_kernel(const uint32_t* __restrict__ cdf_g,
+                                                       uint64_t seed, uint64_t first_index,
+                                                       uint8_t* __restrict__ out, uint64_t n) {
+  __shared__ uint32_t cdf[256];
+  cdf[threadIdx.x] = cdf_g[threadIdx.x];
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
+  for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += stride) {
+    const uint64_t left = n - base;
+    if (left >= 16 && (((uintptr_t)(out + base)) & 15) == 0) {
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          x |= sample_byte(cdf, seed, first_index + base + 4 * j + k) << (8 * k);
+        w[j] = x;
+      }
+      *(uint4*)(out + base) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      const uint32_t m = left < 16 ? (uint32_t)left : 16;
+      for (uint32_t j = 0; j < m; ++j)
+        out[base + j] = (uint8_t)sample_byte(cdf, seed, first_index + base + j);
+    }
+  }
+}
+
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+
+int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                     uint64_t n_frames, uint32_t* d_hist, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  uint64_t bpf = (frame_bytes + (1u << 16) - 1) >> 16;  // ~64 KiB of input per block
+  if (bpf < 1) bpf = 1;
+  if (bpf > 65536) bpf = 65536;
+  if (n_frames * bpf > 0x7fffffffull) return hipErrorInvalidValue;
+  if (bpf > 1) {
+    hipError_t e = hipMemsetAsync(d_hist, 0, n_frames * 256 * sizeof(uint32_t), as_stream(stream));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(hist_kernel, dim3((uint32_t)(n_frames * bpf)), dim3(256), 0,
+                     as_stream(stream), d_raw, total, frame_bytes, (uint32_t)bpf, d_hist);
+  return hipGetLastError();
+}
+
+int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                        uint64_t n_frames, const FrameCode* d_code, uint32_t* d_stream_end,
+                        uint32_t* d_csize, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                     (uint32_t)K, d_raw, total, frame_bytes, d_code, d_stream_end, d_csize);
+  return hipGetLastError();
+}
+
+int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
+                         uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                         int32_t* d_status, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_csize, n_frames,
+                     comp_stride, comp_cap, d_comp_off, d_comp_size, d_status);
+  return hipGetLastError();
+}
+
+int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                  uint64_t n_frames, const FrameCode* d_code, const uint32_t* d_stream_end,
+                  const uint64_t* d_comp_off, const uint32_t* d_comp_size, uint8_t* d_comp,
+                  uint64_t comp_cap, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                     (uint32_t)K, d_raw, total, frame_bytes, d_code, d_stream_end, d_comp_off,
+                     d_comp_size, d_comp, comp_cap);
+  return hipGetLastError();
+}
+
+int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
+                  const uint32_t* d_comp_size, uint64_t n_frames, uint8_t* d_raw,
+                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(decode_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                     (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
+                     frame_bytes, d_status);
+  return hipGetLastError();
+}
+
+int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, uint8_t* d_out,
+                    uint64_t n, void* stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(generate_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+                     d_cdf, seed, first_index, d_out, n);
+  return hipGetLastError();
+}
+
+}  // namespace hfz

@@ -1,0 +1,153 @@
+/*
+ * hfz -- K-stream static Huffman codec on AMD MI355X (gfx950), C ABI.
+ *
+ * Drop-in replacement for the scalar codec path of ahartik/huffman-avx512:
+ * the frames this library writes are byte-identical to what the reference's
+ * CompressMulti<K> (codec/huffman.cpp:738-846) writes for the same input and
+ * K, and it decodes every frame the reference writes (DecompressMulti<K>,
+ * codec/huffman.cpp:892-960).  K is not stored in a frame; both sides must
+ * agree on it, as in the reference.
+ *
+ * All entry points are plain C: pointers, sizes, integer return codes.
+ * Return value 0 (HFZ_OK) is success; negative values are errors (the
+ * reference asserts/aborts instead, codec/huffman.cpp:715, README.md:142-146).
+ *
+ * The encode/decode/histogram work runs on the GPU.  There is no CPU
+ * fallback: without a usable HIP device every compute entry point returns
+ * HFZ_E_NO_DEVICE.
+ */
+#ifndef HFZ_H_
+#define HFZ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  HFZ_OK = 0,
+  HFZ_E_ARG = -1,        /* bad argument (null pointer, K out of range, ...) */
+  HFZ_E_CAPACITY = -2,   /* destination too small */
+  HFZ_E_CORRUPT = -3,    /* frame header or stream offsets are inconsistent */
+  HFZ_E_NO_DEVICE = -4,  /* no HIP device / HIP runtime error at start-up */
+  HFZ_E_HIP = -5,        /* a HIP call failed (hfz_last_hip_error has it) */
+  HFZ_E_TOO_LARGE = -6,  /* frame larger than HFZ_MAX_FRAME_BYTES */
+  HFZ_E_WORKSPACE = -7   /* workspace smaller than hfz_workspace_bytes() */
+};
+
+/* Stream counts accepted by the GPU kernels: one wavefront lane per stream.
+ * The reference instantiates K in {1,2,4,8,16,32} (scalar) and
+ * {8,...,48} (AVX-512), codec/huffman.cpp:1977-2004. */
+#define HFZ_MAX_STREAMS 64
+/* One frame: raw_size is a u32 and stream offsets are int in the reference
+ * (codec/huffman.cpp:772, 799); the per-stream bit count is formed in 32-bit
+ * arithmetic there (:778), which is exact below 2^28 bytes. */
+#define HFZ_MAX_FRAME_BYTES ((size_t)268435455)
+
+const char* hfz_version(void);
+const char* hfz_strerror(int code);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char* hfz_last_hip_error(void);
+/* Number of HIP devices usable by the library (0 if none). */
+int hfz_device_count(void);
+
+/* ---- host-buffer, single-frame API ------------------------------------- */
+
+/* Largest possible frame for n raw bytes at K streams:
+ * 8 + 13 + 256 + 4(K-1) + ceil(12n/8) + 9K. */
+size_t hfz_compress_bound(size_t n, int K);
+
+/* Replaces huffman::CompressMulti<K>(raw) (codec/huffman.h:9-10,
+ * codec/huffman.cpp:738-846).  src/dst are host pointers; the frame is built
+ * on the current HIP device and copied back. */
+int hfz_compress(int K, const void* src, size_t n, void* dst, size_t cap, size_t* out_n);
+
+/* Replaces huffman::DecompressMulti<K>(compressed) (codec/huffman.h:11-12,
+ * codec/huffman.cpp:892-960).  The raw size comes from header word 0. */
+int hfz_decompress(int K, const void* src, size_t n, void* dst, size_t cap, size_t* out_n);
+
+/* Header word 0 (codec/huffman.cpp:717, 799). */
+int hfz_decompressed_size(const void* src, size_t n, size_t* raw_size);
+
+/* Replaces huffman::MakeHistogram(str) (codec/histogram.h:12,
+ * codec/histogram.cpp:193-201): 256 byte counts, computed on the GPU. */
+int hfz_histogram(const void* src, size_t n, uint32_t hist[256]);
+
+/* ---- canonical code table (host side, 256 symbols) --------------------- */
+
+/* Everything CompressMulti derives from the total histogram
+ * (MakeCanonicalCoding, codec/huffman.cpp:339-437): per-symbol code and
+ * length, canonical symbol order, per-length counts. */
+typedef struct hfz_code_table {
+  uint16_t bits[256];      /* code, left-aligned in 12 bits (BitCode.bits) */
+  uint8_t len[256];        /* code length 0..12; 0 also for absent symbols */
+  uint8_t sorted_syms[256];
+  uint16_t len_count[13];
+  uint16_t num_syms;
+  uint32_t len_mask;
+} hfz_code_table;
+
+/* Pure host function (no GPU needed).  Bit-exact with MakeCanonicalCoding,
+ * including the order of equal-count symbols (std::sort call of
+ * codec/huffman.cpp:353-354). */
+int hfz_build_code_table(const uint32_t hist[256], hfz_code_table* out);
+
+/* ---- device-resident batch API (the measured path) --------------------- */
+/*
+ * A batch is one contiguous raw buffer of `total` bytes cut into frames of
+ * `frame_bytes` (the last one may be shorter; total == 0 gives one empty
+ * frame).  Frame i is exactly CompressMulti<K>(raw[i*frame_bytes, ...)).
+ * All d_* pointers are device pointers on the current device; `stream` is a
+ * hipStream_t (NULL = default stream).  Calls are asynchronous on `stream`
+ * unless stated otherwise.
+ */
+size_t hfz_batch_frames(size_t total, size_t frame_bytes);
+size_t hfz_workspace_bytes(int K, size_t n_frames);
+
+/*
+ * comp_stride == 0: frames are packed back to back in d_comp in frame order.
+ * comp_stride  > 0: frame i starts at i*comp_stride (must be >=
+ *                   hfz_compress_bound(frame_bytes, K)).
+ * d_comp_off[i] (u64) and d_comp_size[i] (u32) receive each frame's start
+ * offset in d_comp and its size.  d_status[i] (may be NULL) receives HFZ_OK
+ * or HFZ_E_CAPACITY per frame.
+ */
+int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                           void* d_comp, size_t comp_cap, size_t comp_stride,
+                           uint64_t* d_comp_off, uint32_t* d_comp_size, int32_t* d_status,
+                           void* d_ws, size_t ws_bytes, void* stream);
+
+/*
+ * Decodes n_frames frames.  Frame i is read from d_comp + d_comp_off[i]
+ * (d_comp_size[i] bytes; all frames must lie inside [d_comp, d_comp+comp_bytes))
+ * and written to d_raw + i*frame_bytes; its header raw size must be
+ * <= min(frame_bytes, raw_cap - i*frame_bytes).  d_status[i] (may be NULL)
+ * receives HFZ_OK, HFZ_E_CORRUPT or HFZ_E_CAPACITY.
+ */
+int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
+                             const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                             size_t n_frames, void* d_raw, size_t raw_cap, size_t frame_bytes,
+                             int32_t* d_status, void* stream);
+
+/* 256 byte counts (u32, wraps at 2^32) of a device buffer into d_hist[256]. */
+int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream);
+
+/* Per-frame histograms: d_hist[i*256 + c] for the batch's frames. */
+int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
+                            uint32_t* d_hist, void* stream);
+
+/*
+ * Deterministic integer-only synthetic source, filled on the device:
+ * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
+ * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).
+ * d_cdf points to 256 u32 on the device.
+ */
+int hfz_generate_dev(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, void* d_out,
+                     size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFZ_H_ */

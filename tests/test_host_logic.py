@@ -1,0 +1,104 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and
+exports what include/hfz.h declares, and the host-side canonical code builder
+is bit-exact with the oracle (MakeCanonicalCoding, codec/huffman.cpp:339-437)."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import CASE_FILES, load_input
+
+hfz = importlib.import_module("huffman-avx512_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "hfz.h")).read()
+    declared = set(re.findall(r"\b(hfz_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(hfz.EXPORTS)
+    L = ctypes.CDLL(hfz.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+def test_version_and_strerror():
+    assert hfz.lib().hfz_version().startswith(b"hfz")
+    assert hfz.lib().hfz_strerror(hfz.HFZ_E_CORRUPT) == b"corrupt frame"
+
+
+def test_compress_bound_matches_formula():
+    for n in (0, 1, 11, 100000, 1 << 20):
+        for K in (1, 4, 32, 64):
+            assert hfz.compress_bound(n, K) == 8 + 13 + 256 + 4 * (K - 1) + (12 * n + 7) // 8 + 9 * K
+            assert hfz.compress_bound(n, K) == oracle.compress_bound(n, K)
+
+
+def test_batch_frames():
+    L = hfz.lib()
+    assert L.hfz_batch_frames(0, 1024) == 1
+    assert L.hfz_batch_frames(1024, 1024) == 1
+    assert L.hfz_batch_frames(1025, 1024) == 2
+    assert L.hfz_workspace_bytes(64, 10) >= 10 * (1024 + 792 + 256 + 4)
+
+
+def _same_table(hist):
+    t = hfz.build_code_table(hist)
+    c = oracle.make_coding(hist)
+    assert t.num_syms == c.num_syms
+    assert t.len_mask == c.len_mask
+    assert bytes(t.sorted_syms)[: c.num_syms] == c.sorted_syms.tobytes()
+    assert list(t.len_count) == list(c.len_count[:13])
+    assert np.array_equal(np.frombuffer(bytes(t.bits), dtype=np.uint16), c.bits)
+    assert np.array_equal(np.frombuffer(bytes(t.len), dtype=np.uint8), c.len.astype(np.uint8))
+
+
+@pytest.mark.parametrize("name", CASE_FILES)
+def test_code_table_matches_oracle_on_reference_cases(name):
+    _same_table(oracle.histogram(load_input(name)))
+
+
+def test_code_table_matches_oracle_on_random_histograms():
+    rng = np.random.default_rng(7)
+    for it in range(3000):
+        nsym = int(rng.integers(1, 257))
+        hist = np.zeros(256, dtype=np.uint32)
+        idx = rng.choice(256, size=nsym, replace=False)
+        mode = it % 6
+        if mode == 0:
+            vals = rng.integers(1, 4, size=nsym)            # tie-heavy
+        elif mode == 1:
+            vals = rng.integers(1, 1000, size=nsym)
+        elif mode == 2:
+            vals = 1 << rng.integers(0, 24, size=nsym)      # deep trees -> length limit
+        elif mode == 3:
+            vals = rng.geometric(0.05, size=nsym)
+        elif mode == 4:
+            vals = np.full(nsym, 5)
+        else:
+            vals = (1.6 ** np.arange(nsym) % (1 << 27)).astype(np.int64) + 1  # Fibonacci-like
+        hist[idx] = vals.astype(np.uint32)
+        _same_table(hist)
+
+
+def test_no_gpu_means_loud_failure():
+    # Without a usable device the compute entry points must refuse, not fall
+    # back to a CPU path.
+    if hfz.lib().hfz_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hfz.HfzError) as e:
+        hfz.compress(4, b"Hello World")
+    assert e.value.code == hfz.HFZ_E_NO_DEVICE
+
+
+def test_argument_errors():
+    L = hfz.lib()
+    got = ctypes.c_size_t()
+    buf = (ctypes.c_uint8 * 64)()
+    assert L.hfz_compress(0, buf, 8, buf, 64, ctypes.byref(got)) == hfz.HFZ_E_ARG
+    assert L.hfz_compress(65, buf, 8, buf, 64, ctypes.byref(got)) == hfz.HFZ_E_ARG
+    assert L.hfz_decompress(4, buf, 4, buf, 64, ctypes.byref(got)) == hfz.HFZ_E_CORRUPT
+    assert L.hfz_decompressed_size(buf, 8, ctypes.byref(got)) == hfz.HFZ_OK and got.value == 0
