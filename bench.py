@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Benchmark of the K-stream Huffman hot path on MI355X.
+
+One step = encode one batch of synthetic frames and decode it again, both
+through the C ABI (hfz_compress_batch_dev / hfz_decompress_batch_dev), with the
+raw input already resident in HBM.  At N GPUs every rank runs its own batch of
+the same size (independent frames, no data-path collective): weak scaling.
+
+Prints one JSON line (rank 0).  `value` = raw MiB that went through encode AND
+decode per second, whole job: N * total / (time per step).  MiB = 2^20 bytes of
+RAW data, the reference's convention (codec/huffman_benchmark.cpp:67,78).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def geometric_cdf():
+    """P(i) = 0.8^i * 0.2 (the biased source of codec/huffman_benchmark.cpp:27-36)
+    as exact integer thresholds floor(2^32 * P(X <= j))."""
+    q = [min(((5 ** (j + 1) - 4 ** (j + 1)) << 32) // 5 ** (j + 1), 0xFFFFFFFF) for j in range(256)]
+    q[255] = 0xFFFFFFFF
+    return np.array(q, dtype=np.uint32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=64, help="K, streams per frame")
+    ap.add_argument("--total-mib", type=int, default=256, help="raw MiB per GPU per step")
+    ap.add_argument("--frame-kib", type=int, default=64, help="raw KiB per frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" %
+                         (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    hfz = importlib.import_module("huffman-avx512_amd")
+    hfz.lib()  # fails loudly if the HIP library is missing
+
+    K = args.streams
+    total = args.total_mib << 20
+    frame_bytes = args.frame_kib << 10
+    cdf = geometric_cdf()
+    raw = hfz.generate(cdf, 1000 + rank, total, device=dev)
+    codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
+    out = torch.empty(total, dtype=torch.uint8, device=dev)
+
+    def step():
+        batch = codec.compress(raw)
+        codec.decompress(batch, out)
+        return batch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    hfz.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch = step()
+    barrier()
+    t1 = time.perf_counter()
+    kt = hfz.timing_read()
+    hfz.timing_enable(False)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed
+    assert torch.equal(out, raw), "round trip mismatch"
+    assert int(codec.status.abs().sum().item()) == 0 and int(codec.dstatus.abs().sum().item()) == 0
+    comp_bytes = batch.compressed_bytes()
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    mib = total / float(1 << 20)
+    value = world * mib / (elapsed / args.steps)
+
+    # per-kernel roofline: algorithmic HBM bytes per launch / mean launch time
+    N, C = float(total), float(comp_bytes)
+    alg_bytes = {"hist": N, "sizes": N, "encode": N + C, "decode": C + N}
+    kernels = {}
+    for name in ("hist", "table", "sizes", "place", "encode", "decode"):
+        ms = kt[name + "_ms"]
+        ent = {"ms": round(ms, 4)}
+        if name in alg_bytes and ms > 0:
+            ent["GBps"] = round(alg_bytes[name] / (ms * 1e-3) / 1e9, 1)
+        kernels[name] = ent
+    dom = max(("hist", "sizes", "encode", "decode"), key=lambda k: kt[k + "_ms"])
+    achieved = alg_bytes[dom] / (kt[dom + "_ms"] * 1e-3) / 1e9 if kt[dom + "_ms"] > 0 else 0.0
+    traffic = None
+    try:
+        with open(args.traffic_json) as f:
+            traffic = json.load(f).get(dom + "_kernel")
+    except (OSError, ValueError):
+        pass
+    enc_ms = sum(kt[k + "_ms"] for k in ("hist", "table", "sizes", "place", "encode"))
+    roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg_bytes[dom]),
+                "launch_ms": round(kt[dom + "_ms"], 4)}
+
+    result = {
+        "metric": "MiB/s encode+decode on 256-sym biased input; achieved HBM GB/s vs peak",
+        "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "1xMI355X-class, %d-stream encode+decode, %d MiB biased-geometric "
+                               "synthetic per GPU, LDS tables" % (K, args.total_mib),
+                   "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
+                   "frames_per_gpu": codec.n_frames, "compressed_over_raw": round(C / N, 4),
+                   "layout": "packed"},
+        "encode_MiBps_kernels": round(mib / (enc_ms * 1e-3), 1) if enc_ms > 0 else None,
+        "decode_MiBps_kernels": round(mib / (kt["decode_ms"] * 1e-3), 1) if kt["decode_ms"] > 0 else None,
+        "kernels": kernels,
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        sample = min(total, 32 << 20)
+        host = raw[:sample].cpu().numpy()
+        tc, td, _ = oracle.time_roundtrip(K, host, frame_bytes, 1)
+        reps = int(max(1, min(200, round(10.0 / max(tc + td, 1e-3)))))
+        tc, td, _ = oracle.time_roundtrip(K, host, frame_bytes, reps)
+        smib = reps * sample / float(1 << 20)
+        result["cpu_baseline"] = {
+            "value": round(smib / (tc + td), 1), "unit": "MiB/s", "cores": 1, "kind": "port",
+            "encode_MiBps": round(smib / tc, 1), "decode_MiBps": round(smib / td, 1),
+            "sample": "first %d MiB of rank 0's batch (%d frames of %d KiB, K=%d), %d repetitions "
+                      "of whole-call compress+decompress with the scalar C restatement of the "
+                      "reference, one thread" % (sample >> 20, sample // frame_bytes,
+                                                 args.frame_kib, K, reps)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

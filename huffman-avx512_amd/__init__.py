@@ -32,7 +32,7 @@ EXPORTS = (
     "hfz_compress_bound", "hfz_compress", "hfz_decompress", "hfz_decompressed_size",
     "hfz_histogram", "hfz_build_code_table", "hfz_batch_frames", "hfz_workspace_bytes",
     "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
-    "hfz_histogram_batch_dev", "hfz_generate_dev",
+    "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
 )
 
 
@@ -47,6 +47,12 @@ class HfzError(RuntimeError):
         except Exception:  # pragma: no cover
             pass
         super().__init__("%s failed: %d %s" % (where, code, detail))
+
+
+class BatchTiming(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in
+                ("hist_ms", "table_ms", "sizes_ms", "place_ms", "encode_ms", "decode_ms")] + [
+                    ("compress_calls", ctypes.c_int32), ("decompress_calls", ctypes.c_int32)]
 
 
 class CodeTable(ctypes.Structure):
@@ -103,6 +109,10 @@ def lib():
         L.hfz_histogram_batch_dev.argtypes = [vp, sz, sz, vp, vp]
         L.hfz_generate_dev.restype = ci
         L.hfz_generate_dev.argtypes = [vp, u64, u64, vp, sz, vp]
+        L.hfz_timing_enable.restype = ci
+        L.hfz_timing_enable.argtypes = [ci]
+        L.hfz_timing_read.restype = ci
+        L.hfz_timing_read.argtypes = [ctypes.POINTER(BatchTiming)]
         _lib = L
     return _lib
 
@@ -254,6 +264,16 @@ class BatchCodec:
             self.frame_bytes, self.dstatus.data_ptr(), self._stream()),
             "hfz_decompress_batch_dev")
         return out[: self.total]
+
+
+def timing_enable(on=True):
+    _check(lib().hfz_timing_enable(1 if on else 0), "hfz_timing_enable")
+
+
+def timing_read():
+    t = BatchTiming()
+    _check(lib().hfz_timing_read(ctypes.byref(t)), "hfz_timing_read")
+    return {n: getattr(t, n) for n, _ in BatchTiming._fields_}
 
 
 def generate(cdf, seed, n, device="cuda", first_index=0):

@@ -26,6 +26,37 @@ int hip_fail(hipError_t e) {
     if (e__ != hipSuccess) return hip_fail(e__); \
   } while (0)
 
+// Per-thread event sets for hfz_timing_*: every batch call made while timing
+// is on takes a fresh set, records an event before and after each of its
+// kernels, and hfz_timing_read averages over all sets taken since the last
+// read.
+constexpr int kEncEvents = 6, kDecEvents = 2, kMaxTimedCalls = 512;
+struct Timing {
+  bool on = false;
+  std::vector<hipEvent_t> enc, dec;  // kEncEvents / kDecEvents per call
+  size_t enc_calls = 0, dec_calls = 0;
+  hipEvent_t* cur = nullptr;
+  hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, int per_call) {
+    cur = nullptr;
+    if (!on || calls >= (size_t)kMaxTimedCalls) return hipSuccess;
+    while (v.size() < (calls + 1) * per_call) {
+      hipEvent_t e;
+      hipError_t r = hipEventCreate(&e);
+      if (r != hipSuccess) return r;
+      v.push_back(e);
+    }
+    cur = &v[calls * per_call];
+    ++calls;
+    return hipSuccess;
+  }
+};
+thread_local Timing g_timing;
+
+hipError_t mark(int i, hipStream_t st) {
+  if (!g_timing.cur) return hipSuccess;
+  return hipEventRecord(g_timing.cur[i], st);
+}
+
 bool have_device() {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -230,7 +261,10 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
   hipStream_t st = (hipStream_t)stream;
   const uint8_t* raw = (const uint8_t*)d_raw;
 
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
+  HFZ_HIP(mark(0, st));
   HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+  HFZ_HIP(mark(1, st));
   // canonical codes on the host, one per frame
   {
     std::vector<uint32_t> hist(nf * 256);
@@ -242,11 +276,16 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
     HFZ_HIP(hipMemcpyAsync(d_code, code.data(), nf * sizeof(FrameCode), hipMemcpyHostToDevice, st));
     HFZ_HIP(hipStreamSynchronize(st));
   }
+  HFZ_HIP(mark(2, st));
   HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_code, d_send, d_csize, stream));
+  HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
                                d_status, stream));
+  HFZ_HIP(mark(4, st));
   HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, d_code, d_send, d_comp_off, d_comp_size,
                         (uint8_t*)d_comp, comp_cap, stream));
+  HFZ_HIP(mark(5, st));
+  g_timing.cur = nullptr;
   return HFZ_OK;
 }
 
@@ -258,8 +297,49 @@ int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
       (raw_cap && !d_raw))
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, kDecEvents));
+  HFZ_HIP(mark(0, (hipStream_t)stream));
   HFZ_HIP(launch_decode(K, (const uint8_t*)d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames,
                         (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
+  HFZ_HIP(mark(1, (hipStream_t)stream));
+  g_timing.cur = nullptr;
+  return HFZ_OK;
+}
+
+int hfz_timing_enable(int on) {
+  g_timing.on = on != 0;
+  g_timing.enc_calls = g_timing.dec_calls = 0;
+  g_timing.cur = nullptr;
+  return HFZ_OK;
+}
+
+int hfz_timing_read(hfz_batch_timing* out) {
+  if (!out) return HFZ_E_ARG;
+  std::memset(out, 0, sizeof(*out));
+  float* dst[5] = {&out->hist_ms, &out->table_ms, &out->sizes_ms, &out->place_ms,
+                   &out->encode_ms};
+  for (size_t c = 0; c < g_timing.enc_calls; ++c) {
+    hipEvent_t* ev = &g_timing.enc[c * kEncEvents];
+    HFZ_HIP(hipEventSynchronize(ev[kEncEvents - 1]));
+    for (int i = 0; i < 5; ++i) {
+      float ms = 0;
+      HFZ_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      *dst[i] += ms;
+    }
+  }
+  for (size_t c = 0; c < g_timing.dec_calls; ++c) {
+    hipEvent_t* ev = &g_timing.dec[c * kDecEvents];
+    HFZ_HIP(hipEventSynchronize(ev[1]));
+    float ms = 0;
+    HFZ_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out->decode_ms += ms;
+  }
+  if (g_timing.enc_calls)
+    for (int i = 0; i < 5; ++i) *dst[i] /= (float)g_timing.enc_calls;
+  if (g_timing.dec_calls) out->decode_ms /= (float)g_timing.dec_calls;
+  out->compress_calls = (int32_t)g_timing.enc_calls;
+  out->decompress_calls = (int32_t)g_timing.dec_calls;
+  g_timing.enc_calls = g_timing.dec_calls = 0;
   return HFZ_OK;
 }
 

@@ -10,10 +10,8 @@ namespace hfz {
 namespace {
 
 typedef uint32_t __attribute__((aligned(1))) u32_u;
-typedef uint64_t __attribute__((aligned(1))) u64_u;
 
 __device__ __forceinline__ uint32_t load_u32u(const uint8_t* p) { return *(const u32_u*)p; }
-__device__ __forceinline__ uint64_t load_u64u(const uint8_t* p) { return *(const u64_u*)p; }
 __device__ __forceinline__ void store_u32u(uint8_t* p, uint32_t v) { *(u32_u*)p = v; }
 
 // SliceSizes<K> (codec/huffman.cpp:98-108) in closed form: slice k of n bytes.
@@ -259,13 +257,73 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // 683-689, 931-953).  Entry layout (u32): bits 0-7 bits consumed,
 // 8-15 first symbol, 16-23 second symbol (0 if none), 24-25 symbol count,
 // 28-31 length of the first code.
+//
+// Global memory is touched only in whole, aligned 32-byte blocks that the wave
+// moves cooperatively (two lanes per stream and block): each stream has a
+// two-block input ring and a two-block output ring in LDS.  A round is
+// kDecRound table lookups per lane, which consume at most one input block and
+// produce at most one output block, so one (masked) block load and one block
+// store per stream and round keep the rings fed.
+constexpr uint32_t kDecBlk = 32;                   // bytes per staged block
+constexpr uint32_t kDecRound = 16;                 // lookups per round (<= 24 B in, <= 32 B out)
+constexpr uint32_t kRingDw = 2 * kDecBlk / 4 + 1;  // row stride in dwords (+1: bank spread)
+constexpr uint32_t kNoBlock = 0xffffffffu;
+
+// Moves one 32-byte block per stream from global memory into the input rings.
+// want = block start (offset from cbase, multiple of 32) or kNoBlock.
+__device__ __forceinline__ void stage_in(uint32_t* iring, const uint8_t* cbase, int64_t min_off,
+                                         uint32_t want, uint32_t lane) {
+#pragma unroll
+  for (uint32_t i = 0; i < 2; ++i) {
+    const uint32_t r = 32 * i + (lane >> 1);
+    const uint32_t c = lane & 1;
+    const uint32_t wb = __shfl(want, r, 64);
+    if (wb != kNoBlock && (int64_t)wb >= min_off) {
+      const uint4 v = *(const uint4*)(cbase + wb + 16 * c);
+      uint32_t* dst = iring + r * kRingDw + (((wb + 16 * c) & (2 * kDecBlk - 1)) >> 2);
+      dst[0] = v.x;
+      dst[1] = v.y;
+      dst[2] = v.z;
+      dst[3] = v.w;
+    }
+  }
+}
+
+// Stores one 32-byte block per stream from the output rings; only bytes inside
+// the stream's slice [rlo, rhi) (offsets from obase) are written.
+__device__ __forceinline__ void stage_out(const uint32_t* oring, uint8_t* obase,
+                                          const uint32_t* rlo, const uint32_t* rhi,
+                                          uint32_t flush, uint32_t lane) {
+#pragma unroll
+  for (uint32_t i = 0; i < 2; ++i) {
+    const uint32_t r = 32 * i + (lane >> 1);
+    const uint32_t c = lane & 1;
+    const uint32_t fb = __shfl(flush, r, 64);
+    if (fb == kNoBlock) continue;
+    const uint32_t lo = rlo[r], hi = rhi[r];
+    const uint32_t a = fb + 16 * c;  // chunk [a, a+16)
+    const uint32_t* src = oring + r * kRingDw + ((a & (2 * kDecBlk - 1)) >> 2);
+    if (a >= lo && a + 16 <= hi) {
+      *(uint4*)(obase + a) = make_uint4(src[0], src[1], src[2], src[3]);
+    } else if (a < hi && a + 16 > lo) {
+      for (uint32_t j = 0; j < 16; ++j) {
+        const uint32_t p = a + j;
+        if (p >= lo && p < hi) obase[p] = (uint8_t)(src[j >> 2] >> (8 * (j & 3)));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
   __shared__ uint32_t tab[4096];
-  __shared__ uint8_t syms[256];
+  __shared__ uint32_t iring[64 * kRingDw];
+  __shared__ uint32_t oring[64 * kRingDw];
+  __shared__ uint32_t rlo[64], rhi[64];
+  uint8_t* syms = (uint8_t*)oring;  // only needed while the table is built
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
 
@@ -339,12 +397,11 @@ __global__ __launch_bounds__(64) void decode_kernel(
     if (L1 + L2 <= (uint32_t)kMaxCodeLen)
       tab[e] = (L1 + L2) | (t & 0xff00) | ((t2 & 0xff00) << 8) | (2u << 24) | (L1 << 28);
   }
-  __syncthreads();
 
-  // stream boundaries (codec/huffman.cpp:897-901)
-  const uint8_t* area = in + hdr_total;
+  // stream boundaries (codec/huffman.cpp:897-901); lanes >= K get an empty
+  // stream so that they can take part in the cooperative block moves
   const uint32_t area_size = size - hdr_total;
-  uint32_t end = 0, begin = 0;
+  uint32_t end = kSlop, begin = 0;
   bool bad = false;
   if (lane < K) {
     const uint8_t* eo = in + 8 + nlen + nsym;
@@ -356,77 +413,165 @@ __global__ __launch_bounds__(64) void decode_kernel(
     if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
     return;
   }
-  if (lane == 0 && status) status[f] = HFZ_OK;
-  if (lane >= K) return;
 
-  const Slice s = slice_of(raw_size, K, lane);
-  uint8_t* out = raw + out_base + s.begin;
-  uint32_t remaining = s.size;  // symbols still to decode
-  int64_t ip = (int64_t)end - 8;  // window start, relative to `area`
-  uint32_t used = 0;
+  // Input side: offsets are relative to cbase, a 32-byte aligned address 64
+  // bytes below the frame so that look-ahead never goes negative.  Blocks that
+  // start below the 32-byte block holding the first byte of `comp` are never
+  // loaded (a valid stream never needs them).
+  const uint8_t* cbase = (const uint8_t*)(((uintptr_t)in & ~uintptr_t(31)) - 64);
+  const int64_t min_off = (int64_t)(((uintptr_t)comp & ~uintptr_t(31)) - (uintptr_t)cbase);
+  const uint32_t area_off = (uint32_t)((uintptr_t)in - (uintptr_t)cbase) + hdr_total;
+  const uint32_t g_end = area_off + end;  // one past the stream's last byte
+  // Output side: offsets relative to obase, the 32-byte block holding the
+  // frame's first output byte.
+  uint8_t* const frame_out = raw + out_base;
+  uint8_t* const obase = (uint8_t*)((uintptr_t)frame_out & ~uintptr_t(31));
+  Slice s;
+  s.begin = 0;
+  s.size = 0;
+  if (lane < K) s = slice_of(raw_size, K, lane);
+  const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
+  rlo[lane] = out_lo;
+  rhi[lane] = out_lo + s.size;
+
+  // prime the input ring with the two blocks below the stream end
+  uint32_t low_blk = (g_end - 1) & ~(kDecBlk - 1);  // lowest block staged so far
+  __syncthreads();  // table complete; syms (aliased on oring) no longer read
+  stage_in(iring, cbase, min_off, low_blk, lane);
+  low_blk -= kDecBlk;
+  stage_in(iring, cbase, min_off, low_blk, lane);
+  __syncthreads();
+
+  // bit reader: bitbuf holds bitcnt valid bits, MSB first; rp = one past the
+  // next (4-byte aligned) dword to fetch from the ring
+  const uint32_t* irow = iring + lane * kRingDw;
+  uint32_t* orow = oring + lane * kRingDw;
+  uint64_t bitbuf = 0;
+  uint32_t bitcnt = 0;
+  uint32_t rp = g_end & ~3u;
+  if (g_end & 3) {
+    const uint32_t w = irow[(rp & (2 * kDecBlk - 1)) >> 2];
+    const uint32_t r = g_end & 3;
+    bitbuf = (uint64_t)(w << (8 * (4 - r))) << 32;
+    bitcnt = 8 * r;
+  }
+  // output: obuf collects bytes, finished dwords go to the ring at wp
   uint64_t obuf = 0;
-  uint32_t ocnt = 0;
+  uint32_t ocnt = out_lo & 3;  // bytes below the slice start in the first dword
+  uint32_t wp = out_lo & ~3u;
+  uint32_t left = s.size;      // symbols still to produce
+  uint32_t next_flush = out_lo & ~(kDecBlk - 1);
+  bool stream_bad = false;
 
-#define HFZ_LOOKUP(win)                                              \
-  do {                                                               \
-    const uint32_t e_ = tab[(uint32_t)(((win) << used) >> 52)];      \
-    obuf |= (uint64_t)((e_ >> 8) & 0xffff) << (8 * ocnt);            \
-    ocnt += (e_ >> 24) & 3;                                          \
-    used += e_ & 0xff;                                               \
+#define HFZ_REFILL()                                              \
+  do {                                                            \
+    if (bitcnt <= 32) {                                           \
+      rp -= 4;                                                    \
+      const uint32_t w_ = irow[(rp & (2 * kDecBlk - 1)) >> 2];    \
+      bitbuf |= (uint64_t)w_ << (32 - bitcnt);                    \
+      bitcnt += 32;                                               \
+    }                                                             \
   } while (0)
-#define HFZ_DRAIN()                      \
-  do {                                   \
-    if (ocnt >= 4) {                     \
-      store_u32u(out, (uint32_t)obuf);   \
-      out += 4;                          \
-      obuf >>= 32;                       \
-      ocnt -= 4;                         \
-    }                                    \
+#define HFZ_DRAIN()                                               \
+  do {                                                            \
+    if (ocnt >= 4) {                                              \
+      orow[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;       \
+      obuf >>= 32;                                                \
+      ocnt -= 4;                                                  \
+      wp += 4;                                                    \
+    }                                                             \
   } while (0)
 
-  // fast loop: two lookups (<= 4 symbols, <= 24 bits) per 8-byte window
-  while (remaining >= 4) {
-    ip -= used >> 3;
-    used &= 7;
-    if (ip < 0) break;
-    const uint64_t win = load_u64u(area + ip);
-    const uint32_t before = ocnt;
-    HFZ_LOOKUP(win);
-    HFZ_LOOKUP(win);
-    remaining -= ocnt - before;
-    HFZ_DRAIN();
-  }
-  // tail: one lookup at a time, window zero-extended below the stream area
-  // (FillBuffer, codec/huffman.cpp:536-556)
-  while (remaining > 0) {
-    ip -= used >> 3;
-    used &= 7;
-    uint64_t win = 0;
-    if (ip >= 0) {
-      win = load_u64u(area + ip);
-    } else if (ip > -8) {
-      win = load_u64u(area) << (8 * (uint32_t)(-ip));
+  while (__any(left > 0)) {
+    // make sure [rp-32, rp) is staged
+    uint32_t want = kNoBlock;
+    if (left > 0) {
+      if (rp < area_off) {  // ran below the stream area: corrupt stream
+        stream_bad = true;
+        left = 0;
+      } else {
+        const uint32_t y = (rp - kDecBlk) & ~(kDecBlk - 1);
+        if (y < low_blk) {
+          want = y;
+          low_blk = y;
+        }
+      }
     }
-    const uint32_t e = tab[(uint32_t)((win << used) >> 52)];
-    uint32_t ns = (e >> 24) & 3;
-    uint32_t pair = (e >> 8) & 0xffff;
-    if (ns > remaining) {  // last symbol of the slice: Decode1 (:875-878)
-      ns = 1;
-      pair &= 0xff;
+    if (__any(want != kNoBlock)) {
+      stage_in(iring, cbase, min_off, want, lane);
+      __syncthreads();
     }
-    obuf |= (uint64_t)pair << (8 * ocnt);
-    ocnt += ns;
-    used += e & 0xff;
-    remaining -= ns;
-    HFZ_DRAIN();
+
+    if (left >= 2 * kDecRound) {
+      // fast round: every lookup may emit two symbols without bounds checks
+      const uint32_t before = ocnt + wp;
+#pragma unroll
+      for (uint32_t j = 0; j < kDecRound / 2; ++j) {
+        HFZ_REFILL();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
+          const uint32_t nb = e & 0xff;
+          bitbuf <<= nb;
+          bitcnt -= nb;
+          obuf |= (uint64_t)((e >> 8) & 0xffff) << (8 * ocnt);
+          ocnt += (e >> 24) & 3;
+        }
+        HFZ_DRAIN();
+      }
+      left -= ocnt + wp - before;
+    } else if (left > 0) {
+      // last symbols of the slice; the final one may be the first half of a
+      // two-symbol entry (Decode1, codec/huffman.cpp:875-878)
+      for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
+        HFZ_REFILL();
+        const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
+        uint32_t ns = (e >> 24) & 3;
+        uint32_t pair = (e >> 8) & 0xffff;
+        if (ns > left) {
+          ns = 1;
+          pair &= 0xff;
+        }
+        const uint32_t nb = e & 0xff;
+        bitbuf <<= nb;
+        bitcnt -= nb < bitcnt ? nb : bitcnt;
+        obuf |= (uint64_t)pair << (8 * ocnt);
+        ocnt += ns;
+        left -= ns;
+        HFZ_DRAIN();
+      }
+    }
+    // store the block that filled up in this round, if any
+    uint32_t flush = kNoBlock;
+    if (wp >= next_flush + kDecBlk) {
+      flush = next_flush;
+      next_flush += kDecBlk;
+    }
+    __syncthreads();
+    if (__any(flush != kNoBlock)) stage_out(oring, obase, rlo, rhi, flush, lane);
+    __syncthreads();
   }
-  while (ocnt > 0) {
-    *out++ = (uint8_t)obuf;
-    obuf >>= 8;
-    --ocnt;
-  }
-#undef HFZ_LOOKUP
+#undef HFZ_REFILL
 #undef HFZ_DRAIN
+  // whatever is left: the last partial dword, then at most two blocks per stream
+  if (ocnt > 0) {
+    orow[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;
+    wp += 4;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    uint32_t flush = kNoBlock;
+    if (wp > next_flush) {
+      flush = next_flush;
+      next_flush += kDecBlk;
+    }
+    stage_out(oring, obase, rlo, rhi, flush, lane);
+  }
+  if (status) {
+    const bool any_bad = __any(stream_bad);
+    if (lane == 0) status[f] = any_bad ? HFZ_E_CORRUPT : HFZ_OK;
+  }
 }
 
 // ---------------------------------------------------------------------------

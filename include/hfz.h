@@ -139,6 +139,28 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
                             uint32_t* d_hist, void* stream);
 
 /*
+ * Optional per-kernel timing of the batch entry points, taken with HIP events
+ * on the caller's stream (used by the benchmark to price each kernel against
+ * its roofline).  hfz_timing_enable(1) makes the following batch calls of this
+ * thread record events (at most 512 calls of each kind between reads);
+ * hfz_timing_read waits for them, returns the mean milliseconds per call of
+ * each kernel over the calls recorded since the previous read, and starts a
+ * new window.  Has no counterpart in the reference.
+ */
+typedef struct hfz_batch_timing {
+  float hist_ms;    /* byte histogram (K1) */
+  float table_ms;   /* canonical code construction */
+  float sizes_ms;   /* per-stream coded sizes (K2) */
+  float place_ms;   /* frame placement (prefix sum) */
+  float encode_ms;  /* encode (K3) */
+  float decode_ms;  /* table build + decode (K4+K5) */
+  int32_t compress_calls;   /* calls averaged into the first five fields */
+  int32_t decompress_calls; /* calls averaged into decode_ms */
+} hfz_batch_timing;
+int hfz_timing_enable(int on);
+int hfz_timing_read(hfz_batch_timing* out);
+
+/*
  * Deterministic integer-only synthetic source, filled on the device:
  * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
  * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).
