@@ -176,21 +176,61 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t* __restric
 
 // ---------------------------------------------------------------------------
 // K3: encode.  Lane k packs slice k MSB-first into a 64-bit accumulator and
-// stores finished 32-bit pieces towards lower addresses, which yields the
-// bytes CodeWriter (codec/huffman.cpp:439-500) leaves behind: bit i of the
-// stream is bit 7-(i&7) of byte end-1-(i>>3); the 8 bytes at the start of the
-// stream region stay zero.
+// emits finished 32-bit pieces towards lower addresses, which yields the bytes
+// CodeWriter (codec/huffman.cpp:439-500) leaves behind: bit i of the stream is
+// bit 7-(i&7) of byte end-1-(i>>3), and the 8 bytes at the start of the stream
+// region are zero.
+//
+// As in the decoder, global memory is touched in whole aligned 32-byte blocks
+// moved by two lanes per stream: a round stages one input block per stream in
+// LDS (the next one is already in flight in registers), every lane encodes its
+// 32 bytes into a 4-block output ring, and the blocks that filled up (at most
+// two per round, 12 bits per symbol) are stored.
+constexpr uint32_t kNoBlock = 0xffffffffu;
+constexpr uint32_t kEncBlk = 32;
+constexpr uint32_t kEncInDw = kEncBlk / 4 + 1;       // input row stride (dwords)
+constexpr uint32_t kEncRing = 4 * kEncBlk;           // output ring bytes per stream
+constexpr uint32_t kEncOutDw = kEncRing / 4 + 1;     // output row stride (dwords)
+
+// Stores one 32-byte block per stream from an output ring; only bytes inside
+// [rlo, rhi) of the stream (offsets from obase) are written.
+template <uint32_t RING_BYTES, uint32_t STRIDE_DW>
+__device__ __forceinline__ void store_blocks(const uint32_t* ring, uint8_t* obase,
+                                             const uint32_t* rlo, const uint32_t* rhi,
+                                             uint32_t flush, uint32_t lane) {
+#pragma unroll
+  for (uint32_t i = 0; i < 2; ++i) {
+    const uint32_t r = 32 * i + (lane >> 1);
+    const uint32_t c = lane & 1;
+    const uint32_t fb = __shfl(flush, r, 64);
+    if (fb == kNoBlock) continue;
+    const uint32_t lo = rlo[r], hi = rhi[r];
+    const uint32_t a = fb + 16 * c;  // chunk [a, a+16)
+    const uint32_t* src = ring + r * STRIDE_DW + ((a & (RING_BYTES - 1)) >> 2);
+    if (a >= lo && a + 16 <= hi) {
+      *(uint4*)(obase + a) = make_uint4(src[0], src[1], src[2], src[3]);
+    } else if (a < hi && a + 16 > lo) {
+      for (uint32_t j = 0; j < 16; ++j) {
+        const uint32_t p = a + j;
+        if (p >= lo && p < hi) obase[p] = (uint8_t)(src[j >> 2] >> (8 * (j & 3)));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     const FrameCode* __restrict__ code, const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
   __shared__ uint16_t enc[256];
+  __shared__ uint32_t iring[64 * kEncInDw];
+  __shared__ uint32_t oring[64 * kEncOutDw];
+  __shared__ uint32_t ilo[64], ihi[64], olo[64], ohi[64];
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   const FrameCode& fc = code[f];
   for (uint32_t i = lane; i < 256; i += 64) enc[i] = fc.enc[i];
-  __syncthreads();
 
   const uint64_t off = comp_off[f];
   const uint32_t size = comp_size[f];
@@ -205,48 +245,159 @@ __global__ __launch_bounds__(64) void encode_kernel(
   for (uint32_t i = lane; i < hdr_len; i += 64) out[4 + i] = fc.hdr[i];
   if (lane < K - 1) store_u32u(out + 4 + hdr_len + 4 * lane, stream_end[f * 64 + lane]);
 
-  if (lane >= K) return;
-  const uint32_t end = stream_end[f * 64 + lane];
-  const uint32_t begin = lane ? stream_end[f * 64 + lane - 1] : 0;
-  uint8_t* rb = out + hdr_total + begin;
-  uint8_t* pos = out + hdr_total + end;
-  store_u32u(rb, 0);
-  store_u32u(rb + 4, 0);
-
-  const Slice s = slice_of(n, K, lane);
-  const uint8_t* p = raw + f * frame_bytes + s.begin;
-  uint64_t acc = 0;
-  uint32_t nb = 0;
-#define HFZ_PUT(byte)                                  \
-  do {                                                 \
-    const uint32_t e_ = enc[(byte)];                   \
-    acc |= (uint64_t)(e_ >> 4) << (52 - nb);           \
-    nb += e_ & 15;                                     \
-    if (nb >= 32) {                                    \
-      pos -= 4;                                        \
-      store_u32u(pos, (uint32_t)(acc >> 32));          \
-      acc <<= 32;                                      \
-      nb -= 32;                                        \
-    }                                                  \
-  } while (0)
-  uint32_t i = 0;
-  const uint32_t cnt = s.size;
-  while (i < cnt && ((uintptr_t)(p + i) & 15)) HFZ_PUT(p[i++]);
-  for (; i + 16 <= cnt; i += 16) {
-    const uint4 v = *(const uint4*)(p + i);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) HFZ_PUT((w[j] >> (8 * k)) & 0xff);
-    }
+  // input rows: offsets from ibase, the 32-byte block holding the frame's
+  // first raw byte; output rows: offsets from obase likewise
+  const uint8_t* const frame_in = raw + f * frame_bytes;
+  const uint8_t* const ibase = (const uint8_t*)((uintptr_t)frame_in & ~uintptr_t(31));
+  uint8_t* const obase = (uint8_t*)((uintptr_t)out & ~uintptr_t(31));
+  Slice s;
+  s.begin = 0;
+  s.size = 0;
+  uint32_t r_lo = 0, r_hi = 0;
+  if (lane < K) {
+    s = slice_of(n, K, lane);
+    const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
+    r_hi = area + stream_end[f * 64 + lane];
+    r_lo = area + (lane ? stream_end[f * 64 + lane - 1] : 0);
   }
-  for (; i < cnt; ++i) HFZ_PUT(p[i]);
+  const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
+  const uint32_t in_hi = in_lo + s.size;
+  ilo[lane] = in_lo;
+  ihi[lane] = in_hi;
+  olo[lane] = r_lo;
+  ohi[lane] = r_hi;
+  __syncthreads();
+
+  const uint32_t my_rounds = s.size ? ((in_hi + kEncBlk - 1) / kEncBlk - in_lo / kEncBlk) : 0;
+  // cooperative loader: lane handles half c of the block of rows r0, r1
+  const uint32_t c = lane & 1;
+  uint32_t lr[2], lblk[2], lhi[2];
+#pragma unroll
+  for (uint32_t i = 0; i < 2; ++i) {
+    lr[i] = 32 * i + (lane >> 1);
+    lblk[i] = (ilo[lr[i]] & ~(kEncBlk - 1)) + 16 * c;
+    lhi[i] = ihi[lr[i]] > ilo[lr[i]] ? ihi[lr[i]] : 0;  // empty slice: never load
+  }
+  uint4 pre[2];
+#pragma unroll
+  for (uint32_t i = 0; i < 2; ++i) {
+    pre[i] = make_uint4(0, 0, 0, 0);
+    if (lblk[i] - 16 * c < lhi[i]) pre[i] = *(const uint4*)(ibase + lblk[i]);
+  }
+
+  const uint32_t* irow = iring + lane * kEncInDw;
+  uint32_t* orow = oring + lane * kEncOutDw;
+  // bit writer: acc holds nb pending bits MSB first; wp = the (4-byte aligned)
+  // address just above the next dword to write.  If the stream does not end on
+  // a dword boundary the bytes above its end count as already "written".
+  uint64_t acc = 0;
+  uint32_t nb = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
+  uint32_t wp = (r_hi + 3) & ~3u;
+  bool nf_live = lane < K;
+  uint32_t nf = (r_hi - 1) & ~(kEncBlk - 1);            // next block to store (descending)
+  const uint32_t nf_last = r_lo & ~(kEncBlk - 1);
+  bool done = lane >= K;
+
+#define HFZ_EMIT()                                                  \
+  do {                                                              \
+    if (nb >= 32) {                                                 \
+      wp -= 4;                                                      \
+      orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);     \
+      acc <<= 32;                                                   \
+      nb -= 32;                                                     \
+    }                                                               \
+  } while (0)
+#define HFZ_PUT(byte)                                               \
+  do {                                                              \
+    const uint32_t e_ = enc[(byte)];                                \
+    acc |= (uint64_t)(e_ >> 4) << (52 - nb);                        \
+    nb += e_ & 15;                                                  \
+  } while (0)
+
+  for (uint32_t t = 0; __any(!done); ++t) {
+    // stage block t, start loading block t+1
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+      uint32_t* dst = iring + lr[i] * kEncInDw + 4 * c;
+      dst[0] = pre[i].x;
+      dst[1] = pre[i].y;
+      dst[2] = pre[i].z;
+      dst[3] = pre[i].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+      lblk[i] += kEncBlk;
+      if (lblk[i] - 16 * c < lhi[i]) pre[i] = *(const uint4*)(ibase + lblk[i]);
+    }
+
+    if (!done) {
+      if (t < my_rounds) {
+        const uint32_t b = (in_lo & ~(kEncBlk - 1)) + kEncBlk * t;
+        if (b >= in_lo && b + kEncBlk <= in_hi) {
+#pragma unroll
+          for (uint32_t d = 0; d < kEncBlk / 4; ++d) {
+            const uint32_t w = irow[d];
+            HFZ_PUT(w & 0xff);
+            HFZ_PUT((w >> 8) & 0xff);
+            HFZ_EMIT();
+            HFZ_PUT((w >> 16) & 0xff);
+            HFZ_PUT(w >> 24);
+            HFZ_EMIT();
+          }
+        } else {
+          for (uint32_t j = 0; j < kEncBlk; ++j) {
+            const uint32_t p = b + j;
+            if (p >= in_lo && p < in_hi) {
+              HFZ_PUT((irow[j >> 2] >> (8 * (j & 3))) & 0xff);
+              HFZ_EMIT();
+            }
+          }
+        }
+      }
+      if (t + 1 >= my_rounds) {
+        // end of stream: pad to a byte, then the 8 zero bytes of slop
+        // (codec/huffman.cpp:770), then the last partial dword
+        nb = (nb + 7) & ~7u;
+        HFZ_EMIT();
+        nb += 32;
+        HFZ_EMIT();
+        nb += 32;
+        HFZ_EMIT();
+        if (nb > 0) {
+          wp -= 4;
+          orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
+          nb = 0;
+        }
+        done = true;
+      }
+    }
+    // store the blocks that are complete (everything at or above wp is written)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      uint32_t flush = kNoBlock;
+      if (nf_live && wp <= nf) {
+        flush = nf;
+        if (nf == nf_last) nf_live = false;
+        nf -= kEncBlk;
+      }
+      if (__any(flush != kNoBlock))
+        store_blocks<kEncRing, kEncOutDw>(oring, obase, olo, ohi, flush, lane);
+    }
+    __syncthreads();
+  }
+#undef HFZ_EMIT
 #undef HFZ_PUT
-  while (nb > 0) {
-    *--pos = (uint8_t)(acc >> 56);
-    acc <<= 8;
-    nb = nb > 8 ? nb - 8 : 0;
+  // the lowest blocks of each stream region (partial, or finished last round)
+  while (__any(nf_live)) {
+    uint32_t flush = kNoBlock;
+    if (nf_live) {
+      flush = nf;
+      if (nf == nf_last) nf_live = false;
+      nf -= kEncBlk;
+    }
+    store_blocks<kEncRing, kEncOutDw>(oring, obase, olo, ohi, flush, lane);
   }
 }
 
@@ -267,7 +418,6 @@ __global__ __launch_bounds__(64) void encode_kernel(
 constexpr uint32_t kDecBlk = 32;                   // bytes per staged block
 constexpr uint32_t kDecRound = 16;                 // lookups per round (<= 24 B in, <= 32 B out)
 constexpr uint32_t kRingDw = 2 * kDecBlk / 4 + 1;  // row stride in dwords (+1: bank spread)
-constexpr uint32_t kNoBlock = 0xffffffffu;
 
 // Moves one 32-byte block per stream from global memory into the input rings.
 // want = block start (offset from cbase, multiple of 32) or kNoBlock.
@@ -285,31 +435,6 @@ __device__ __forceinline__ void stage_in(uint32_t* iring, const uint8_t* cbase, 
       dst[1] = v.y;
       dst[2] = v.z;
       dst[3] = v.w;
-    }
-  }
-}
-
-// Stores one 32-byte block per stream from the output rings; only bytes inside
-// the stream's slice [rlo, rhi) (offsets from obase) are written.
-__device__ __forceinline__ void stage_out(const uint32_t* oring, uint8_t* obase,
-                                          const uint32_t* rlo, const uint32_t* rhi,
-                                          uint32_t flush, uint32_t lane) {
-#pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    const uint32_t r = 32 * i + (lane >> 1);
-    const uint32_t c = lane & 1;
-    const uint32_t fb = __shfl(flush, r, 64);
-    if (fb == kNoBlock) continue;
-    const uint32_t lo = rlo[r], hi = rhi[r];
-    const uint32_t a = fb + 16 * c;  // chunk [a, a+16)
-    const uint32_t* src = oring + r * kRingDw + ((a & (2 * kDecBlk - 1)) >> 2);
-    if (a >= lo && a + 16 <= hi) {
-      *(uint4*)(obase + a) = make_uint4(src[0], src[1], src[2], src[3]);
-    } else if (a < hi && a + 16 > lo) {
-      for (uint32_t j = 0; j < 16; ++j) {
-        const uint32_t p = a + j;
-        if (p >= lo && p < hi) obase[p] = (uint8_t)(src[j >> 2] >> (8 * (j & 3)));
-      }
     }
   }
 }
@@ -548,7 +673,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
       next_flush += kDecBlk;
     }
     __syncthreads();
-    if (__any(flush != kNoBlock)) stage_out(oring, obase, rlo, rhi, flush, lane);
+    if (__any(flush != kNoBlock)) store_blocks<2 * kDecBlk, kRingDw>(oring, obase, rlo, rhi, flush, lane);
     __syncthreads();
   }
 #undef HFZ_REFILL
@@ -566,7 +691,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
       flush = next_flush;
       next_flush += kDecBlk;
     }
-    stage_out(oring, obase, rlo, rhi, flush, lane);
+    store_blocks<2 * kDecBlk, kRingDw>(oring, obase, rlo, rhi, flush, lane);
   }
   if (status) {
     const bool any_bad = __any(stream_bad);
