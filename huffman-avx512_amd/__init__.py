@@ -33,6 +33,7 @@ EXPORTS = (
     "hfz_histogram", "hfz_build_code_table", "hfz_batch_frames", "hfz_workspace_bytes",
     "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
+    "hfz_frame_code_from_table", "hfz_build_codes_dev",
 )
 
 
@@ -53,6 +54,11 @@ class BatchTiming(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in
                 ("hist_ms", "table_ms", "sizes_ms", "place_ms", "encode_ms", "decode_ms")] + [
                     ("compress_calls", ctypes.c_int32), ("decompress_calls", ctypes.c_int32)]
+
+
+class FrameCode(ctypes.Structure):
+    _fields_ = [("enc", ctypes.c_uint16 * 256), ("hdr", ctypes.c_uint8 * 276),
+                ("hdr_len", ctypes.c_uint32)]
 
 
 class CodeTable(ctypes.Structure):
@@ -109,6 +115,10 @@ def lib():
         L.hfz_histogram_batch_dev.argtypes = [vp, sz, sz, vp, vp]
         L.hfz_generate_dev.restype = ci
         L.hfz_generate_dev.argtypes = [vp, u64, u64, vp, sz, vp]
+        L.hfz_frame_code_from_table.restype = ci
+        L.hfz_frame_code_from_table.argtypes = [ctypes.POINTER(CodeTable), ctypes.POINTER(FrameCode)]
+        L.hfz_build_codes_dev.restype = ci
+        L.hfz_build_codes_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_timing_enable.restype = ci
         L.hfz_timing_enable.argtypes = [ci]
         L.hfz_timing_read.restype = ci
@@ -177,6 +187,29 @@ def build_code_table(hist):
     t = CodeTable()
     _check(lib().hfz_build_code_table(h.ctypes.data, ctypes.byref(t)), "hfz_build_code_table")
     return t
+
+
+def frame_code(hist):
+    """Host-built encoder record (enc table + header bytes) for one histogram."""
+    t = build_code_table(hist)
+    fc = FrameCode()
+    _check(lib().hfz_frame_code_from_table(ctypes.byref(t), ctypes.byref(fc)),
+           "hfz_frame_code_from_table")
+    return fc
+
+
+def build_codes_dev(hists):
+    """Device-built encoder records for an (n, 256) uint32 array of histograms;
+    returns an (n, 792) uint8 numpy array of hfz_frame_code records."""
+    import torch
+    h = np.ascontiguousarray(hists, dtype=np.uint32).reshape(-1, 256)
+    n = h.shape[0]
+    d_h = torch.as_tensor(h.view(np.int32)).cuda()
+    d_c = torch.zeros(n * ctypes.sizeof(FrameCode), dtype=torch.uint8, device="cuda")
+    _check(lib().hfz_build_codes_dev(d_h.data_ptr(), n, d_c.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "hfz_build_codes_dev")
+    torch.cuda.synchronize()
+    return d_c.cpu().numpy().reshape(n, ctypes.sizeof(FrameCode))
 
 
 class HuffmanCompressorGpu:

@@ -156,9 +156,7 @@ static void make_code_table(const uint32_t hist[256], hfz_code_table* t) {
   }
 }
 
-void build_frame_code(const uint32_t hist[256], FrameCode* out) {
-  hfz_code_table t;
-  make_code_table(hist, &t);
+static void frame_code_from_table(const hfz_code_table& t, FrameCode* out) {
   for (int c = 0; c < 256; ++c) out->enc[c] = (uint16_t)((t.bits[c] << 4) | t.len[c]);
   // header bytes after raw_size: len_mask, counts (256 -> 0x00), symbols (:800-808)
   uint8_t* p = out->hdr;
@@ -170,6 +168,12 @@ void build_frame_code(const uint32_t hist[256], FrameCode* out) {
   p += t.num_syms;
   out->hdr_len = (uint32_t)(p - out->hdr);
   std::memset(p, 0, sizeof(out->hdr) - out->hdr_len);
+}
+
+void build_frame_code(const uint32_t hist[256], FrameCode* out) {
+  hfz_code_table t;
+  make_code_table(hist, &t);
+  frame_code_from_table(t, out);
 }
 
 }  // namespace hfz
@@ -265,17 +269,7 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
   HFZ_HIP(mark(0, st));
   HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
   HFZ_HIP(mark(1, st));
-  // canonical codes on the host, one per frame
-  {
-    std::vector<uint32_t> hist(nf * 256);
-    std::vector<FrameCode> code(nf);
-    HFZ_HIP(hipMemcpyAsync(hist.data(), d_hist, nf * 256 * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HFZ_HIP(hipStreamSynchronize(st));
-    for (size_t f = 0; f < nf; ++f) build_frame_code(&hist[f * 256], &code[f]);
-    HFZ_HIP(hipMemcpyAsync(d_code, code.data(), nf * sizeof(FrameCode), hipMemcpyHostToDevice, st));
-    HFZ_HIP(hipStreamSynchronize(st));
-  }
+  HFZ_HIP(launch_build_codes(d_hist, nf, d_code, stream));
   HFZ_HIP(mark(2, st));
   HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_code, d_send, d_csize, stream));
   HFZ_HIP(mark(3, st));
@@ -303,6 +297,19 @@ int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
                         (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
   HFZ_HIP(mark(1, (hipStream_t)stream));
   g_timing.cur = nullptr;
+  return HFZ_OK;
+}
+
+int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_codes, void* stream) {
+  static_assert(sizeof(hfz_frame_code) == sizeof(FrameCode), "public and internal layout differ");
+  if (!d_hist || !d_codes) return HFZ_E_ARG;
+  HFZ_HIP(launch_build_codes(d_hist, n, (FrameCode*)d_codes, stream));
+  return HFZ_OK;
+}
+
+int hfz_frame_code_from_table(const hfz_code_table* t, hfz_frame_code* out) {
+  if (!t || !out) return HFZ_E_ARG;
+  frame_code_from_table(*t, (FrameCode*)out);
   return HFZ_OK;
 }
 

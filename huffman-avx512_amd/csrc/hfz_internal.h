@@ -55,6 +55,7 @@ void build_frame_code(const uint32_t hist[256], FrameCode* out);
 // Kernel launchers (hfz_kernels.hip).  All return a hipError_t as int.
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                      uint64_t n_frames, uint32_t* d_hist, void* stream);
+int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream);
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const FrameCode* d_code, uint32_t* d_stream_end,
                         uint32_t* d_csize, void* stream);

@@ -92,6 +92,293 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ r
 }
 
 // ---------------------------------------------------------------------------
+// Canonical code construction on the device, one wave per frame:
+// MakeCanonicalCoding (codec/huffman.cpp:339-437) from the frame's histogram.
+//
+// The order of equal-count symbols is part of the frame (it decides
+// sorted_syms and with it every code), and the reference gets it from
+// libstdc++'s std::sort (:353-354), so that algorithm is followed step by
+// step: the introsort partition loop (median of three to the front, unguarded
+// Hoare partition, segments of at most 16 left alone, heapsort once the depth
+// budget 2*floor(log2 n) is spent) runs serially on lane 0; the insertion sort
+// that finishes std::sort is stable, so its result is the stable order of the
+// partitioned array and all lanes compute it as ranks.  The two-queue Huffman
+// merge (:364-416, a leaf wins a tie, :375) is serial as well; depths come from
+// parent links by pointer jumping.
+struct SortArrays {
+  uint8_t* sym;
+  uint32_t* key;
+};
+__device__ __forceinline__ bool sort_less(const SortArrays& a, int i, int j) {
+  return a.key[i] > a.key[j];  // comparator of codec/huffman.cpp:354
+}
+__device__ __forceinline__ void sort_swap(const SortArrays& a, int i, int j) {
+  const uint8_t s = a.sym[i];
+  const uint32_t k = a.key[i];
+  a.sym[i] = a.sym[j];
+  a.key[i] = a.key[j];
+  a.sym[j] = s;
+  a.key[j] = k;
+}
+__device__ __forceinline__ void sort_move(const SortArrays& a, int dst, int src) {
+  a.sym[dst] = a.sym[src];
+  a.key[dst] = a.key[src];
+}
+
+// std::__adjust_heap + std::__push_heap on [first, first+len), value (vs, vk)
+__device__ void heap_adjust(const SortArrays& a, int first, int hole, int len, uint8_t vs,
+                            uint32_t vk) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (sort_less(a, first + child, first + child - 1)) child--;
+    sort_move(a, first + hole, first + child);
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    sort_move(a, first + hole, first + child - 1);
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && a.key[first + parent] > vk) {
+    sort_move(a, first + hole, first + parent);
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  a.sym[first + hole] = vs;
+  a.key[first + hole] = vk;
+}
+
+// std::__partial_sort(first, last, last): make_heap then sort_heap
+__device__ void heap_sort_range(const SortArrays& a, int first, int last) {
+  const int len = last - first;
+  if (len >= 2) {
+    for (int parent = (len - 2) / 2;; --parent) {
+      heap_adjust(a, first, parent, len, a.sym[first + parent], a.key[first + parent]);
+      if (parent == 0) break;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    const uint8_t vs = a.sym[last];
+    const uint32_t vk = a.key[last];
+    sort_move(a, last, first);
+    heap_adjust(a, first, 0, last - first, vs, vk);
+  }
+}
+
+// std::__introsort_loop with its recursion on an explicit stack
+__device__ void introsort_loop(const SortArrays& a, int n, int* stk) {
+  int depth = 0;
+  for (int v = n; v > 1; v >>= 1) ++depth;
+  depth *= 2;
+  int sp = 0, first = 0, last = n;
+  for (;;) {
+    while (last - first > 16) {
+      if (depth == 0) {
+        heap_sort_range(a, first, last);
+        break;
+      }
+      --depth;
+      // __move_median_to_first(first, first+1, mid, last-1)
+      const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+      int m;
+      if (sort_less(a, x, y)) {
+        m = sort_less(a, y, z) ? y : (sort_less(a, x, z) ? z : x);
+      } else {
+        m = sort_less(a, x, z) ? x : (sort_less(a, y, z) ? z : y);
+      }
+      sort_swap(a, first, m);
+      // __unguarded_partition(first+1, last, first)
+      const uint32_t pk = a.key[first];
+      int i = first + 1, j = last;
+      for (;;) {
+        while (a.key[i] > pk) ++i;
+        --j;
+        while (pk > a.key[j]) --j;
+        if (!(i < j)) break;
+        sort_swap(a, i, j);
+        ++i;
+      }
+      // recurse on [i, last) with the reduced depth, continue with [first, i)
+      stk[3 * sp] = i;
+      stk[3 * sp + 1] = last;
+      stk[3 * sp + 2] = depth;
+      ++sp;
+      last = i;
+    }
+    if (sp == 0) return;
+    --sp;
+    first = stk[3 * sp];
+    last = stk[3 * sp + 1];
+    depth = stk[3 * sp + 2];
+  }
+}
+
+__global__ __launch_bounds__(64) void code_kernel(const uint32_t* __restrict__ hist,
+                                                  FrameCode* __restrict__ code) {
+  __shared__ uint32_t key[256], key2[256], tcount[256], lcount[256];
+  __shared__ uint8_t sym[256], sym2[256];
+  __shared__ uint16_t parent[2][256], depthv[2][256], lparent[256], encs[256];
+  __shared__ uint32_t hdrw[70];
+  __shared__ int stk[3 * 40];
+  __shared__ int tree_size_s;
+  const uint64_t f = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+
+  // symbols with a nonzero count, ascending (:342-347)
+  const uint4 h4 = *(const uint4*)(hist + f * 256 + 4 * lane);
+  const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
+  uint32_t nz = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nz += hv[j] != 0;
+  const uint32_t incl = wave_inclusive_scan(nz, lane);
+  const int n = (int)__shfl(incl, 63, 64);
+  uint32_t pos = incl - nz;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lcount[4 * lane + j] = 0;
+    encs[4 * lane + j] = 0;
+    if (hv[j] != 0) {
+      sym[pos] = (uint8_t)(4 * lane + j);
+      key[pos] = hv[j];
+      ++pos;
+    }
+  }
+  __syncthreads();
+
+  const SortArrays arr = {sym, key};
+  if (lane == 0 && n > 16) introsort_loop(arr, n, stk);
+  __syncthreads();
+  // stable order by descending count = what the final insertion sort leaves
+  for (int i = (int)lane; i < n; i += 64) {
+    const uint32_t k = key[i];
+    int rank = 0;
+    for (int m = 0; m < n; ++m) {
+      const uint32_t km = key[m];
+      rank += (km > k) || (km == k && m < i);
+    }
+    sym2[rank] = sym[i];
+    key2[rank] = k;
+  }
+  __syncthreads();
+
+  // two-queue Huffman merge; records each leaf's and node's parent
+  if (lane == 0) {
+    int ns = n - 1, nt = 0, ts = 0;
+    while ((ts - nt) + (ns + 1) > 1) {
+      uint32_t sum = 0;
+      for (int t = 0; t < 2; ++t) {
+        bool leaf = false;
+        if (ns >= 0) leaf = nt == ts || key2[ns] <= tcount[nt];
+        if (leaf) {
+          sum += key2[ns];
+          lparent[ns--] = (uint16_t)ts;
+        } else {
+          sum += tcount[nt];
+          parent[0][nt++] = (uint16_t)ts;
+        }
+      }
+      tcount[ts++] = sum;
+    }
+    tree_size_s = ts;
+    if (ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
+  }
+  __syncthreads();
+  const int ts = tree_size_s;
+  if (ts == 0) {
+    if (lane == 0 && n == 1) lcount[0] = 1;  // a single symbol: zero-length code
+  } else {
+    // depth of every internal node by pointer jumping (root = ts-1, depth 0)
+    for (int i = (int)lane; i < ts; i += 64) depthv[0][i] = i == ts - 1 ? 0 : 1;
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < 8; ++it) {
+      for (int i = (int)lane; i < ts; i += 64) {
+        const int p = parent[cur][i];
+        depthv[cur ^ 1][i] = (uint16_t)(depthv[cur][i] + depthv[cur][p]);
+        parent[cur ^ 1][i] = parent[cur][p];
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    for (int i = (int)lane; i < n; i += 64)
+      atomicAdd(&lcount[depthv[cur][lparent[i]] + 1], 1u);
+  }
+  __syncthreads();
+
+  // LimitCodeLengths (:297-327)
+  if (lane == 0 && n > 0) {
+    uint32_t over = 0;
+    for (int i = kMaxCodeLen + 1; i < 256; ++i) over += lcount[i];
+    lcount[kMaxCodeLen] += over;
+    uint32_t kraft = 0;
+    for (int i = 0; i <= kMaxCodeLen; ++i) kraft += lcount[i] << (kMaxCodeLen - i);
+    while (kraft > (1u << kMaxCodeLen)) {
+      --lcount[kMaxCodeLen];
+      for (int j = kMaxCodeLen - 1; j >= 0; --j) {
+        if (lcount[j] > 0) {
+          --lcount[j];
+          lcount[j + 1] += 2;
+          break;
+        }
+      }
+      --kraft;
+    }
+  }
+  __syncthreads();
+
+  // canonical codes in sorted order (ForallCodes, :260-284) and header bytes
+  uint32_t lc[kMaxCodeLen + 1];
+  uint32_t len_mask = 0, nlen = 0;
+#pragma unroll
+  for (int L = 0; L <= kMaxCodeLen; ++L) {
+    lc[L] = lcount[L];
+    if (lc[L]) {
+      len_mask |= 1u << L;
+      ++nlen;
+    }
+  }
+  for (int i = (int)lane; i < n; i += 64) {
+    uint32_t start = 0, codev = 0, L = 0, base = 0, fc = 0;
+#pragma unroll
+    for (int l = 0; l <= kMaxCodeLen; ++l) {
+      if ((uint32_t)i >= start && lc[l] != 0) {
+        L = l;
+        base = start;
+        fc = codev;
+      }
+      start += lc[l];
+      codev += lc[l] << (kMaxCodeLen - l);
+    }
+    const uint32_t c12 = fc + (((uint32_t)i - base) << (kMaxCodeLen - L));
+    encs[sym2[i]] = (uint16_t)((c12 << 4) | L);
+  }
+  uint8_t* hb = (uint8_t*)hdrw;
+  for (uint32_t i = lane; i < 70; i += 64) hdrw[i] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    hdrw[0] = len_mask;
+    uint32_t p = 4;
+#pragma unroll
+    for (int L = 0; L <= kMaxCodeLen; ++L)
+      if (lc[L]) hb[p++] = (uint8_t)lc[L];  // 256 is stored as 0x00 (:801-806)
+  }
+  for (int i = (int)lane; i < n; i += 64) hb[4 + nlen + i] = sym2[i];
+  __syncthreads();
+
+  FrameCode& out = code[f];
+  uint32_t* enc_out = (uint32_t*)out.enc;
+  const uint32_t* encs32 = (const uint32_t*)encs;
+  for (uint32_t i = lane; i < 128; i += 64) enc_out[i] = encs32[i];
+  uint32_t* hdr_out = (uint32_t*)out.hdr;
+  for (uint32_t i = lane; i < 69; i += 64) hdr_out[i] = hdrw[i];
+  if (lane == 0) out.hdr_len = 4 + nlen + (uint32_t)n;
+}
+
+// ---------------------------------------------------------------------------
 // K2: coded size of every stream of a frame (codec/huffman.cpp:770-786):
 // size_k = ceil(sum of code lengths over slice k / 8) + 8, then prefix sums.
 __device__ __forceinline__ uint32_t sum_code_len(const uint8_t* p, uint32_t n,
@@ -768,6 +1055,14 @@ int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
   }
   hipLaunchKernelGGL(hist_kernel, dim3((uint32_t)(n_frames * bpf)), dim3(256), 0,
                      as_stream(stream), d_raw, total, frame_bytes, (uint32_t)bpf, d_hist);
+  return hipGetLastError();
+}
+
+int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(code_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream), d_hist,
+                     d_code);
   return hipGetLastError();
 }
 

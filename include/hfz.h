@@ -94,6 +94,25 @@ typedef struct hfz_code_table {
  * codec/huffman.cpp:353-354). */
 int hfz_build_code_table(const uint32_t hist[256], hfz_code_table* out);
 
+/* What the encoder kernels consume per frame: enc[c] = (code << 4) | len with
+ * the code left-aligned in 12 bits (the packing of the reference's permute
+ * encoder, codec/huffman.cpp:1095-1111) and the header bytes that follow
+ * raw_size in a frame (len_mask, per-length counts, canonical symbol order;
+ * codec/huffman.cpp:800-808). */
+typedef struct hfz_frame_code {
+  uint16_t enc[256];
+  uint8_t hdr[276];
+  uint32_t hdr_len;
+} hfz_frame_code;
+
+/* Host: hfz_code_table -> hfz_frame_code. */
+int hfz_frame_code_from_table(const hfz_code_table* table, hfz_frame_code* out);
+
+/* Device twin of hfz_build_code_table + hfz_frame_code_from_table, one record
+ * per 256-bin histogram: d_codes[i] from d_hist[i*256 ...].  This is the
+ * kernel the batch encoder runs between its histogram and encode passes. */
+int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_codes, void* stream);
+
 /* ---- device-resident batch API (the measured path) --------------------- */
 /*
  * A batch is one contiguous raw buffer of `total` bytes cut into frames of

@@ -234,3 +234,57 @@ def test_full_size_round_trip_properties(torch_cuda):
         chunk = raw[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().tobytes()
         o, s = int(offs[i].item()), int(sizes[i].item())
         assert host_comp[o:o + s].cpu().numpy().tobytes() == oracle.compress(K, chunk)
+
+
+# ---- device-side canonical code construction --------------------------------
+
+def _random_hists(n, seed):
+    rng = np.random.default_rng(seed)
+    hs = np.zeros((n, 256), dtype=np.uint32)
+    for it in range(n):
+        nsym = int(rng.integers(1, 257))
+        idx = rng.choice(256, size=nsym, replace=False)
+        mode = it % 7
+        if mode == 0:
+            vals = rng.integers(1, 4, size=nsym)
+        elif mode == 1:
+            vals = rng.integers(1, 1000, size=nsym)
+        elif mode == 2:
+            vals = 1 << rng.integers(0, 24, size=nsym)
+        elif mode == 3:
+            vals = rng.geometric(0.05, size=nsym)
+        elif mode == 4:
+            vals = np.full(nsym, 5)
+        elif mode == 5:
+            vals = (1.6 ** np.arange(nsym) % (1 << 27)).astype(np.int64) + 1
+        else:
+            vals = rng.integers(1, 1 << 31, size=nsym)
+        hs[it, idx] = vals.astype(np.uint32)
+    return hs
+
+
+def _killer_hists():
+    """Median-of-three killer sequences: they drive std::sort into its heapsort
+    fallback, which the device code has to follow as well."""
+    out = []
+    for n in range(18, 257, 2):
+        v = np.zeros(n, dtype=np.int64)
+        k = n // 2
+        for i in range(1, k + 1):
+            if i % 2 == 1:
+                v[i - 1] = i
+                v[i] = k + i
+            v[k + i - 1] = 2 * i
+        h = np.zeros(256, dtype=np.uint32)
+        h[:n] = (100000 - v).astype(np.uint32)
+        out.append(h)
+    return np.stack(out)
+
+
+def test_device_code_builder_matches_host(torch_cuda):
+    hs = np.concatenate([_random_hists(4000, 11), _killer_hists(),
+                         np.stack([oracle.histogram(load_input(n)) for n in CASE_FILES])])
+    dev = hfz.build_codes_dev(hs)
+    for i in range(hs.shape[0]):
+        want = bytes(hfz.frame_code(hs[i]))
+        assert dev[i].tobytes() == want, i
