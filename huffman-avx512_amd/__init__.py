@@ -299,6 +299,18 @@ class BatchCodec:
         return out[: self.total]
 
 
+def shard_frames(n_frames, rank, world):
+    """Contiguous range [lo, hi) of frame indices that `rank` of `world` owns.
+    Frames are independent units (own header, table and streams), so sharding a
+    batch over GPUs needs no exchange: every rank encodes/decodes its range and
+    results are concatenated by frame index."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    q, r = divmod(n_frames, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
 def timing_enable(on=True):
     _check(lib().hfz_timing_enable(1 if on else 0), "hfz_timing_enable")
 

@@ -288,3 +288,22 @@ def test_device_code_builder_matches_host(torch_cuda):
     for i in range(hs.shape[0]):
         want = bytes(hfz.frame_code(hs[i]))
         assert dev[i].tobytes() == want, i
+
+
+def test_reference_style_typed_suite_cpp(torch_cuda):
+    # codec/huffman_test.cpp re-created over huffman::HuffmanCompressorGpu<K>
+    # (include/huffman_gpu.h), built by __graft_entry__.build()
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "bin", "compressor_suite")
+    if not os.path.exists(exe):  # normally built by __graft_entry__.build()
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17",
+                               os.path.join(root, "tests", "native", "compressor_suite.cpp"),
+                               "-o", exe, "-L", os.path.join(root, "huffman-avx512_amd"), "-lhfz",
+                               "-Wl,-rpath,$ORIGIN/../../../huffman-avx512_amd"])
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "inputs")],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 failed" in out.stdout
