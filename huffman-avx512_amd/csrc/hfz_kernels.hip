@@ -26,6 +26,40 @@ __device__ __forceinline__ Slice slice_of(uint32_t n, uint32_t K, uint32_t k) {
   return s;
 }
 
+// Diagnostic build only (-DHFZ_STAMP): per-phase cycle sums of the decode
+// kernel, read back with hfz_debug_stamps().  Never compiled into libhfz.so.
+#ifdef HFZ_STAMP
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL() unsigned long long st_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[8] = {}
+#define STAMP(i)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    st_acc_[i] += now_ - st_prev_;                                  \
+    st_prev_ = now_;                                                \
+  } while (0)
+#define STAMP_FLUSH()                                               \
+  do {                                                              \
+    if (threadIdx.x == 0)                                           \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[i_], st_acc_[i_]); \
+  } while (0)
+#else
+#define STAMP_DECL() do {} while (0)
+#define STAMP(i) do {} while (0)
+#define STAMP_FLUSH() do {} while (0)
+#endif
+
+// Ordering point between LDS accesses of different lanes of ONE wave.  The
+// codec kernels run one wave per workgroup; a wave's LDS instructions execute in
+// issue order, so all that is needed is that the compiler keeps the order.
+// __syncthreads() would also wait for every global load and store in flight
+// (s_waitcnt vmcnt(0)), which serialises each round on HBM latency.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t frame_len(uint64_t total, uint64_t frame_bytes, uint64_t f) {
   const uint64_t fb = f * frame_bytes;
   const uint64_t left = total > fb ? total - fb : 0;
@@ -62,8 +96,8 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ r
   const uint64_t hi = lo + piece < n ? lo + piece : n;
   const uint8_t* s = raw + f * frame_bytes + lo;
   const uint8_t* e = raw + f * frame_bytes + hi;
-  const uint8_t* a0 = (const uint8_t*)(((uintptr_t)s + 15) & ~uintptr_t(15));
-  const uint8_t* a1 = (const uint8_t*)((uintptr_t)e & ~uintptr_t(15));
+  const uint8_t* a0 = s + ((16 - ((uintptr_t)s & 15)) & 15);  // pointer arithmetic keeps
+  const uint8_t* a1 = e - ((uintptr_t)e & 15);               // the global address space
   const uint32_t rep = tid & 7;
   if (a0 >= a1) {
     for (const uint8_t* q = s + tid; q < e; q += 256) atomicAdd(&h[(uint32_t)*q * 8 + rep], 1u);
@@ -535,8 +569,8 @@ __global__ __launch_bounds__(64) void encode_kernel(
   // input rows: offsets from ibase, the 32-byte block holding the frame's
   // first raw byte; output rows: offsets from obase likewise
   const uint8_t* const frame_in = raw + f * frame_bytes;
-  const uint8_t* const ibase = (const uint8_t*)((uintptr_t)frame_in & ~uintptr_t(31));
-  uint8_t* const obase = (uint8_t*)((uintptr_t)out & ~uintptr_t(31));
+  const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);  // keeps the address space
+  uint8_t* const obase = out - ((uintptr_t)out & 31);
   Slice s;
   s.begin = 0;
   s.size = 0;
@@ -553,7 +587,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
   ihi[lane] = in_hi;
   olo[lane] = r_lo;
   ohi[lane] = r_hi;
-  __syncthreads();
+  wave_sync();
 
   const uint32_t my_rounds = s.size ? ((in_hi + kEncBlk - 1) / kEncBlk - in_lo / kEncBlk) : 0;
   // cooperative loader: lane handles half c of the block of rows r0, r1
@@ -611,7 +645,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
       dst[2] = pre[i].z;
       dst[3] = pre[i].w;
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (uint32_t i = 0; i < 2; ++i) {
       lblk[i] += kEncBlk;
@@ -660,7 +694,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
       }
     }
     // store the blocks that are complete (everything at or above wp is written)
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       uint32_t flush = kNoBlock;
@@ -672,7 +706,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
       if (__any(flush != kNoBlock))
         store_blocks<kEncRing, kEncOutDw>(oring, obase, olo, ohi, flush, lane);
     }
-    __syncthreads();
+    wave_sync();
   }
 #undef HFZ_EMIT
 #undef HFZ_PUT
@@ -692,39 +726,22 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // K4 + K5: decode.  The 4096-entry two-symbol table of Decoder2x
 // (codec/huffman.cpp:644-681) is rebuilt in LDS from the frame header, then
 // lane k decodes stream k (CodeReader + Decode, codec/huffman.cpp:502-586,
-// 683-689, 931-953).  Entry layout (u32): bits 0-7 bits consumed,
-// 8-15 first symbol, 16-23 second symbol (0 if none), 24-25 symbol count,
-// 28-31 length of the first code.
+// 683-689, 931-953).  Entry layout (u32): byte 0 first symbol, byte 1 bits
+// consumed, byte 2 second symbol (0 if none), byte 3 symbol count.
 //
-// Global memory is touched only in whole, aligned 32-byte blocks that the wave
-// moves cooperatively (two lanes per stream and block): each stream has a
-// two-block input ring and a two-block output ring in LDS.  A round is
-// kDecRound table lookups per lane, which consume at most one input block and
-// produce at most one output block, so one (masked) block load and one block
-// store per stream and round keep the rings fed.
-constexpr uint32_t kDecBlk = 32;                   // bytes per staged block
-constexpr uint32_t kDecRound = 16;                 // lookups per round (<= 24 B in, <= 32 B out)
-constexpr uint32_t kRingDw = 2 * kDecBlk / 4 + 1;  // row stride in dwords (+1: bank spread)
-
-// Moves one 32-byte block per stream from global memory into the input rings.
-// want = block start (offset from cbase, multiple of 32) or kNoBlock.
-__device__ __forceinline__ void stage_in(uint32_t* iring, const uint8_t* cbase, int64_t min_off,
-                                         uint32_t want, uint32_t lane) {
-#pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    const uint32_t r = 32 * i + (lane >> 1);
-    const uint32_t c = lane & 1;
-    const uint32_t wb = __shfl(want, r, 64);
-    if (wb != kNoBlock && (int64_t)wb >= min_off) {
-      const uint4 v = *(const uint4*)(cbase + wb + 16 * c);
-      uint32_t* dst = iring + r * kRingDw + (((wb + 16 * c) & (2 * kDecBlk - 1)) >> 2);
-      dst[0] = v.x;
-      dst[1] = v.y;
-      dst[2] = v.z;
-      dst[3] = v.w;
-    }
-  }
-}
+// Every lane moves its own stream between global memory and LDS in whole,
+// aligned 32-byte blocks (two 16-byte accesses): per stream LDS holds a
+// two-block input ring (plus an 8-byte mirror of its first bytes so that a
+// 12-byte read never wraps) and a linear three-block output row.  A round is
+// kDecRound lookups: it consumes at most 24 input bytes and produces at most
+// 32 output bytes, so one block load (issued when the previous block was
+// staged, into registers) and one block store per round keep up.  Streams of
+// one frame lie n/K bytes apart, so neighbouring lanes never share a cache
+// line anyway; what matters is that each line is moved in few, aligned pieces.
+constexpr uint32_t kDecBlk = 32;     // bytes per staged block
+constexpr uint32_t kDecRound = 16;   // lookups per round
+constexpr uint32_t kDecInDw = 19;    // input row: 64 B ring + 8 B mirror + 4 B pad
+constexpr uint32_t kDecOutDw = 25;   // output row: 96 B + 4 B slack
 
 __global__ __launch_bounds__(64) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
@@ -732,12 +749,16 @@ __global__ __launch_bounds__(64) void decode_kernel(
     uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
   __shared__ uint32_t tab[4096];
-  __shared__ uint32_t iring[64 * kRingDw];
-  __shared__ uint32_t oring[64 * kRingDw];
-  __shared__ uint32_t rlo[64], rhi[64];
-  uint8_t* syms = (uint8_t*)oring;  // only needed while the table is built
+  __shared__ uint32_t ringmem[64 * (kDecInDw + kDecOutDw)];
+  uint32_t* const iring = ringmem;
+  uint32_t* const obuf = ringmem + 64 * kDecInDw;
+  // scratch that is only live while the table is built
+  uint8_t* const l1tab = (uint8_t*)ringmem;  // first-code length per table index (on iring)
+  static_assert(sizeof(uint32_t) * 64 * kDecInDw >= 4096, "l1tab fits in the input rings");
+  static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
+  STAMP_DECL();
 
   const uint64_t off = comp_off[f];
   const uint32_t size = comp_size[f];
@@ -747,8 +768,25 @@ __global__ __launch_bounds__(64) void decode_kernel(
     return;
   }
   const uint8_t* in = comp + off;
-  const uint32_t raw_size = load_u32u(in);
-  const uint32_t len_mask = load_u32u(in + 4);
+  // One round trip brings the whole header (at most 8 + 13 + 256 + 4*63 bytes)
+  // into LDS; everything below parses it from there.
+  uint32_t* const hdrw = obuf;  // 192 dwords, dead once the streams start
+  const uint8_t* const hb = (const uint8_t*)hdrw;
+#pragma unroll
+  for (uint32_t j = 0; j < 3; ++j) {
+    const uint32_t idx = lane + 64 * j;
+    uint32_t v = 0;
+    if (4 * idx + 4 <= size) {
+      v = load_u32u(in + 4 * idx);
+    } else {
+      for (uint32_t b = 0; b < 4; ++b)
+        if (4 * idx + b < size) v |= (uint32_t)in[4 * idx + b] << (8 * b);
+    }
+    hdrw[idx] = v;
+  }
+  wave_sync();
+  const uint32_t raw_size = hdrw[0];
+  const uint32_t len_mask = hdrw[1];
   const uint64_t out_base = f * frame_bytes;
   uint64_t room = out_base <= raw_cap ? raw_cap - out_base : 0;
   if (room > frame_bytes) room = frame_bytes;
@@ -768,7 +806,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   for (int L = 0; L <= kMaxCodeLen; ++L) {
     uint32_t c = 0;
     if ((len_mask >> L) & 1) {
-      c = in[hp++];
+      c = hb[hp++];
       if (c == 0 && nlen == 1) c = 256;  // 256 is stored as 0 (:724-728)
     }
     cnt[L] = c;
@@ -785,30 +823,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
     if (lane == 0 && status) status[f] = err;
     return;
   }
-
-  for (uint32_t i = lane; i < nsym; i += 64) syms[i] = in[8 + nlen + i];
-  __syncthreads();
-  // single-symbol entries, one code-length class at a time
-#pragma unroll
-  for (int L = 0; L <= kMaxCodeLen; ++L) {
-    if (cnt[L] == 0) continue;
-    const uint32_t lo = fcode[L], hi = fcode[L + 1];
-    for (uint32_t e = lo + lane; e < hi; e += 64) {
-      const uint32_t j = soff[L] + ((e - lo) >> (kMaxCodeLen - L));
-      tab[e] = (uint32_t)L | ((uint32_t)syms[j] << 8) | (1u << 24) | ((uint32_t)L << 28);
-    }
-  }
-  __syncthreads();
-  // second symbol where both codes fit in 12 bits.  Bits 8-15 and 28-31 of an
-  // entry never change, so reading another lane's entry mid-update is safe.
-  for (uint32_t e = lane; e < 4096; e += 64) {
-    const uint32_t t = tab[e];
-    const uint32_t L1 = t >> 28;
-    const uint32_t t2 = tab[(e << L1) & 0xfff];
-    const uint32_t L2 = t2 >> 28;
-    if (L1 + L2 <= (uint32_t)kMaxCodeLen)
-      tab[e] = (L1 + L2) | (t & 0xff00) | ((t2 & 0xff00) << 8) | (2u << 24) | (L1 << 28);
-  }
+  const uint8_t* const syms = hb + 8 + nlen;  // canonical symbol order
 
   // stream boundaries (codec/huffman.cpp:897-901); lanes >= K get an empty
   // stream so that they can take part in the cooperative block moves
@@ -816,170 +831,226 @@ __global__ __launch_bounds__(64) void decode_kernel(
   uint32_t end = kSlop, begin = 0;
   bool bad = false;
   if (lane < K) {
-    const uint8_t* eo = in + 8 + nlen + nsym;
-    end = lane < K - 1 ? load_u32u(eo + 4 * lane) : area_size;
-    begin = lane ? load_u32u(eo + 4 * (lane - 1)) : 0;
+    const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
+    if (lane < K - 1) {
+      const uint32_t p = eo + 4 * lane;
+      end = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
+    } else {
+      end = area_size;
+    }
+    if (lane) {
+      const uint32_t p = eo + 4 * (lane - 1);
+      begin = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
+    }
     bad = end > area_size || begin > end || end - begin < (uint32_t)kSlop;
   }
   if (__any(bad)) {
     if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
     return;
   }
+  STAMP(0);  // header
+
+  // single-symbol entries, one code-length class at a time
+#pragma unroll
+  for (int L = 0; L <= kMaxCodeLen; ++L) {
+    if (cnt[L] == 0) continue;
+    const uint32_t lo = fcode[L], hi = fcode[L + 1];
+#pragma unroll 4
+    for (uint32_t e = lo + lane; e < hi; e += 64) {
+      const uint32_t j = soff[L] + ((e - lo) >> (kMaxCodeLen - L));
+      tab[e] = (uint32_t)syms[j] | ((uint32_t)L << 8) | (1u << 24);
+      l1tab[e] = (uint8_t)L;
+    }
+  }
+  wave_sync();
+  // second symbol where both codes fit in 12 bits.  Byte 0 of an entry and
+  // l1tab never change in this pass, so reading another lane's entry while it
+  // is being rewritten is safe.
+#pragma unroll 8
+  for (uint32_t e = lane; e < 4096; e += 64) {
+    const uint32_t L1 = l1tab[e];
+    const uint32_t rem = (e << L1) & 0xfff;
+    const uint32_t L2 = l1tab[rem];
+    if (L1 + L2 <= (uint32_t)kMaxCodeLen)
+      tab[e] = (tab[e] & 0xff) | ((L1 + L2) << 8) | ((tab[rem] & 0xff) << 16) | (2u << 24);
+  }
+  STAMP(1);  // table
 
   // Input side: offsets are relative to cbase, a 32-byte aligned address 64
   // bytes below the frame so that look-ahead never goes negative.  Blocks that
   // start below the 32-byte block holding the first byte of `comp` are never
   // loaded (a valid stream never needs them).
-  const uint8_t* cbase = (const uint8_t*)(((uintptr_t)in & ~uintptr_t(31)) - 64);
+  const uint8_t* cbase = in - ((uintptr_t)in & 31) - 64;  // pointer arithmetic: stays a global pointer
   const int64_t min_off = (int64_t)(((uintptr_t)comp & ~uintptr_t(31)) - (uintptr_t)cbase);
   const uint32_t area_off = (uint32_t)((uintptr_t)in - (uintptr_t)cbase) + hdr_total;
   const uint32_t g_end = area_off + end;  // one past the stream's last byte
   // Output side: offsets relative to obase, the 32-byte block holding the
   // frame's first output byte.
   uint8_t* const frame_out = raw + out_base;
-  uint8_t* const obase = (uint8_t*)((uintptr_t)frame_out & ~uintptr_t(31));
+  uint8_t* const obase = frame_out - ((uintptr_t)frame_out & 31);
   Slice s;
   s.begin = 0;
   s.size = 0;
   if (lane < K) s = slice_of(raw_size, K, lane);
   const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
-  rlo[lane] = out_lo;
-  rhi[lane] = out_lo + s.size;
+  const uint32_t out_hi = out_lo + s.size;
 
-  // prime the input ring with the two blocks below the stream end
-  uint32_t low_blk = (g_end - 1) & ~(kDecBlk - 1);  // lowest block staged so far
-  __syncthreads();  // table complete; syms (aliased on oring) no longer read
-  stage_in(iring, cbase, min_off, low_blk, lane);
-  low_blk -= kDecBlk;
-  stage_in(iring, cbase, min_off, low_blk, lane);
-  __syncthreads();
+  uint32_t* const irow = iring + lane * kDecInDw;
+  uint32_t* const orow32 = obuf + lane * kDecOutDw;
+  uint8_t* const orow = (uint8_t*)orow32;
+  wave_sync();  // table complete; the scratch aliased on the rings is dead
 
-  // bit reader: bitbuf holds bitcnt valid bits, MSB first; rp = one past the
-  // next (4-byte aligned) dword to fetch from the ring
-  const uint32_t* irow = iring + lane * kRingDw;
-  uint32_t* orow = oring + lane * kRingDw;
-  uint64_t bitbuf = 0;
-  uint32_t bitcnt = 0;
-  uint32_t rp = g_end & ~3u;
-  if (g_end & 3) {
-    const uint32_t w = irow[(rp & (2 * kDecBlk - 1)) >> 2];
-    const uint32_t r = g_end & 3;
-    bitbuf = (uint64_t)(w << (8 * (4 - r))) << 32;
-    bitcnt = 8 * r;
-  }
-  // output: obuf collects bytes, finished dwords go to the ring at wp
-  uint64_t obuf = 0;
-  uint32_t ocnt = out_lo & 3;  // bytes below the slice start in the first dword
-  uint32_t wp = out_lo & ~3u;
-  uint32_t left = s.size;      // symbols still to produce
-  uint32_t next_flush = out_lo & ~(kDecBlk - 1);
-  bool stream_bad = false;
-
-#define HFZ_REFILL()                                              \
+  // loads block `blk` (offset from cbase) of this lane's stream into registers
+  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+#define HFZ_LOAD_BLOCK(blk)                                       \
   do {                                                            \
-    if (bitcnt <= 32) {                                           \
-      rp -= 4;                                                    \
-      const uint32_t w_ = irow[(rp & (2 * kDecBlk - 1)) >> 2];    \
-      bitbuf |= (uint64_t)w_ << (32 - bitcnt);                    \
-      bitcnt += 32;                                               \
+    if ((int64_t)(blk) >= min_off) {                              \
+      pre0 = *(const uint4*)(cbase + (blk));                      \
+      pre1 = *(const uint4*)(cbase + (blk) + 16);                 \
     }                                                             \
   } while (0)
-#define HFZ_DRAIN()                                               \
+  // writes the registers into ring slot of block `blk`
+#define HFZ_STAGE_BLOCK(blk)                                      \
   do {                                                            \
-    if (ocnt >= 4) {                                              \
-      orow[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;       \
-      obuf >>= 32;                                                \
-      ocnt -= 4;                                                  \
-      wp += 4;                                                    \
+    uint32_t* d_ = irow + (((blk) & kDecBlk) >> 2);               \
+    d_[0] = pre0.x; d_[1] = pre0.y; d_[2] = pre0.z; d_[3] = pre0.w; \
+    d_[4] = pre1.x; d_[5] = pre1.y; d_[6] = pre1.z; d_[7] = pre1.w; \
+    if (((blk) & kDecBlk) == 0) {                                 \
+      irow[16] = pre0.x;                                          \
+      irow[17] = pre0.y;                                          \
     }                                                             \
+  } while (0)
+
+  // prime the ring with the two blocks below the stream end, start the third
+  uint32_t low_blk = (g_end - 1) & ~(kDecBlk - 1);  // lowest block staged so far
+  HFZ_LOAD_BLOCK(low_blk);
+  HFZ_STAGE_BLOCK(low_blk);
+  low_blk -= kDecBlk;
+  HFZ_LOAD_BLOCK(low_blk);
+  HFZ_STAGE_BLOCK(low_blk);
+  HFZ_LOAD_BLOCK(low_blk - kDecBlk);
+  STAMP(2);  // priming
+
+  // bit reader (CodeReader, codec/huffman.cpp:502-586): the window is the 8
+  // bytes at ip; `used` bits of it are consumed.  bitbuf = window << used.
+  uint32_t ip = g_end - 8;
+  uint32_t used = 0;
+  uint64_t bitbuf = 0;
+  // output: bytes go to orow[wa], wa counts from the start of the row; the row
+  // starts at output offset row0 (32-byte aligned), `fl` blocks of it are stored
+  uint32_t wa = out_lo & (kDecBlk - 1);
+  uint32_t row0 = out_lo & ~(kDecBlk - 1);
+  uint32_t fl = 0;
+  uint32_t left = s.size;  // symbols still to produce
+  bool stream_bad = false;
+
+#define HFZ_WINDOW()                                                         \
+  do {                                                                       \
+    ip -= used >> 3;                                                         \
+    used &= 7;                                                               \
+    const uint32_t* w_ = irow + ((ip & (2 * kDecBlk - 1)) >> 2);             \
+    const uint32_t d0_ = w_[0], d1_ = w_[1], d2_ = w_[2];                    \
+    const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, ip & 3);       \
+    const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, ip & 3);       \
+    bitbuf = (((uint64_t)hi_ << 32) | lo_) << used;                          \
+  } while (0)
+  // stores block slot `slot` of the output row (output offset row0 + 32*slot);
+  // only bytes of this stream's slice [out_lo, out_hi) are written
+#define HFZ_STORE_BLOCK(slot)                                                \
+  do {                                                                       \
+    const uint32_t a_ = row0 + kDecBlk * (slot);                             \
+    const uint32_t* s_ = orow32 + (kDecBlk / 4) * (slot);                    \
+    if (a_ >= out_lo && a_ + kDecBlk <= out_hi) {                            \
+      *(uint4*)(obase + a_) = make_uint4(s_[0], s_[1], s_[2], s_[3]);        \
+      *(uint4*)(obase + a_ + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]);   \
+    } else {                                                                 \
+      for (uint32_t j_ = 0; j_ < kDecBlk; ++j_) {                            \
+        const uint32_t p_ = a_ + j_;                                         \
+        if (p_ >= out_lo && p_ < out_hi) obase[p_] = orow[kDecBlk * (slot) + j_]; \
+      }                                                                      \
+    }                                                                        \
   } while (0)
 
   while (__any(left > 0)) {
-    // make sure [rp-32, rp) is staged
-    uint32_t want = kNoBlock;
     if (left > 0) {
-      if (rp < area_off) {  // ran below the stream area: corrupt stream
+      // make sure every window of this round, [ip-18, ip+8), is staged
+      ip -= used >> 3;
+      used &= 7;
+      if (ip < area_off) {  // ran below the stream area: corrupt stream
         stream_bad = true;
         left = 0;
-      } else {
-        const uint32_t y = (rp - kDecBlk) & ~(kDecBlk - 1);
-        if (y < low_blk) {
-          want = y;
-          low_blk = y;
-        }
+      } else if (((ip - 18) & ~(kDecBlk - 1)) < low_blk) {
+        low_blk -= kDecBlk;
+        HFZ_STAGE_BLOCK(low_blk);
+        HFZ_LOAD_BLOCK(low_blk - kDecBlk);
       }
     }
-    if (__any(want != kNoBlock)) {
-      stage_in(iring, cbase, min_off, want, lane);
-      __syncthreads();
-    }
-
+    STAMP(3);  // staging
     if (left >= 2 * kDecRound) {
       // fast round: every lookup may emit two symbols without bounds checks
-      const uint32_t before = ocnt + wp;
+      const uint32_t before = wa;
 #pragma unroll
-      for (uint32_t j = 0; j < kDecRound / 2; ++j) {
-        HFZ_REFILL();
+      for (uint32_t j = 0; j < kDecRound / 4; ++j) {
+        HFZ_WINDOW();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 4; ++t) {
           const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-          const uint32_t nb = e & 0xff;
+          orow[wa] = (uint8_t)e;
+          orow[wa + 1] = (uint8_t)(e >> 16);
+          wa += e >> 24;
+          const uint32_t nb = (e >> 8) & 0xff;
           bitbuf <<= nb;
-          bitcnt -= nb;
-          obuf |= (uint64_t)((e >> 8) & 0xffff) << (8 * ocnt);
-          ocnt += (e >> 24) & 3;
+          used += nb;
         }
-        HFZ_DRAIN();
       }
-      left -= ocnt + wp - before;
+      left -= wa - before;
     } else if (left > 0) {
       // last symbols of the slice; the final one may be the first half of a
       // two-symbol entry (Decode1, codec/huffman.cpp:875-878)
       for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-        HFZ_REFILL();
+        if ((j & 3) == 0) HFZ_WINDOW();
         const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-        uint32_t ns = (e >> 24) & 3;
-        uint32_t pair = (e >> 8) & 0xffff;
-        if (ns > left) {
-          ns = 1;
-          pair &= 0xff;
-        }
-        const uint32_t nb = e & 0xff;
-        bitbuf <<= nb;
-        bitcnt -= nb < bitcnt ? nb : bitcnt;
-        obuf |= (uint64_t)pair << (8 * ocnt);
-        ocnt += ns;
+        uint32_t ns = e >> 24;
+        if (ns > left) ns = 1;
+        orow[wa] = (uint8_t)e;
+        orow[wa + 1] = (uint8_t)(e >> 16);
+        wa += ns;
         left -= ns;
-        HFZ_DRAIN();
+        const uint32_t nb = (e >> 8) & 0xff;
+        bitbuf <<= nb;
+        used += nb;
       }
     }
-    // store the block that filled up in this round, if any
-    uint32_t flush = kNoBlock;
-    if (wp >= next_flush + kDecBlk) {
-      flush = next_flush;
-      next_flush += kDecBlk;
-    }
-    __syncthreads();
-    if (__any(flush != kNoBlock)) store_blocks<2 * kDecBlk, kRingDw>(oring, obase, rlo, rhi, flush, lane);
-    __syncthreads();
-  }
-#undef HFZ_REFILL
-#undef HFZ_DRAIN
-  // whatever is left: the last partial dword, then at most two blocks per stream
-  if (ocnt > 0) {
-    orow[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;
-    wp += 4;
-  }
-  __syncthreads();
+    STAMP(4);  // lookups
+    // store the block that filled up in this round, if any; after two blocks
+    // move the rest of the row back to its start
+    if (wa >= kDecBlk * (fl + 1)) {
+      HFZ_STORE_BLOCK(fl);
+      ++fl;
+      if (fl == 2) {
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    uint32_t flush = kNoBlock;
-    if (wp > next_flush) {
-      flush = next_flush;
-      next_flush += kDecBlk;
+        for (uint32_t d = 0; d < kDecOutDw - 16; ++d) orow32[d] = orow32[16 + d];
+        wa -= 2 * kDecBlk;
+        row0 += 2 * kDecBlk;
+        fl = 0;
+      }
     }
-    store_blocks<2 * kDecBlk, kRingDw>(oring, obase, rlo, rhi, flush, lane);
+    STAMP(5);  // block store + row shift
   }
+  // whatever is left in the row: up to three (partial) blocks
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    if (wa > kDecBlk * fl) {
+      HFZ_STORE_BLOCK(fl);
+      ++fl;
+    }
+  }
+#undef HFZ_WINDOW
+#undef HFZ_STORE_BLOCK
+#undef HFZ_LOAD_BLOCK
+#undef HFZ_STAGE_BLOCK
+  STAMP(7);  // tail
+  STAMP_FLUSH();
   if (status) {
     const bool any_bad = __any(stream_bad);
     if (lane == 0) status[f] = any_bad ? HFZ_E_CORRUPT : HFZ_OK;
@@ -1117,5 +1188,16 @@ int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, 
                      d_cdf, seed, first_index, d_out, n);
   return hipGetLastError();
 }
+
+#ifdef HFZ_STAMP
+extern "C" int hfz_debug_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 }  // namespace hfz

@@ -1,0 +1,27 @@
+"""Diagnostic: per-phase cycle shares of decode_kernel (needs tools/libhfz_stamp.so,
+built with -DHFZ_STAMP).  Not part of the product or the tests."""
+import ctypes, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+hfz = importlib.import_module("huffman-avx512_amd")
+hfz.LIB_PATH = os.path.join(ROOT, "tools", "libhfz_stamp.so")
+L = hfz.lib()
+from bench import geometric_cdf
+names = ["header", "table", "priming", "staging", "lookups", "store", "shift", "tail"]
+for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
+    total = 256 << 20
+    raw = hfz.generate(geometric_cdf(), 1000, total)
+    codec = hfz.BatchCodec(64, total, frame_kib << 10)
+    batch = codec.compress(raw)
+    out = torch.empty(total, dtype=torch.uint8, device="cuda")
+    codec.decompress(batch, out); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    L.hfz_debug_stamps(buf, 1)
+    codec.decompress(batch, out); torch.cuda.synchronize()
+    L.hfz_debug_stamps(buf, 1)
+    tot = sum(buf[:8]); nf = codec.n_frames
+    print("frame_kib", frame_kib, "frames", nf, "cycles/wave %.0f" % (tot / nf),
+          " ".join("%s=%.1f%%" % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)))
+    print("equal:", bool(torch.equal(out, raw)))
