@@ -38,15 +38,15 @@ __device__ unsigned long long g_stamps[16];
     st_acc_[i] += now_ - st_prev_;                                  \
     st_prev_ = now_;                                                \
   } while (0)
-#define STAMP_FLUSH()                                               \
+#define STAMP_FLUSH(base)                                           \
   do {                                                              \
     if (threadIdx.x == 0)                                           \
-      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[i_], st_acc_[i_]); \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[(base) + i_], st_acc_[i_]); \
   } while (0)
 #else
 #define STAMP_DECL() do {} while (0)
 #define STAMP(i) do {} while (0)
-#define STAMP_FLUSH() do {} while (0)
+#define STAMP_FLUSH(base) do {} while (0)
 #endif
 
 // Ordering point between LDS accesses of different lanes of ONE wave.  The
@@ -58,6 +58,25 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stores the part of the aligned 32-byte block [a, a+32) (offsets from base,
+// data in src[0..7]) that lies inside [lo, hi): whole dwords where possible,
+// single bytes only in the two dwords that straddle lo or hi.
+__device__ __forceinline__ void store_block_clipped(uint8_t* base, uint32_t a, const uint32_t* src,
+                                                    uint32_t lo, uint32_t hi) {
+#pragma unroll
+  for (uint32_t d = 0; d < 8; ++d) {
+    const uint32_t p = a + 4 * d;
+    const uint32_t w = src[d];
+    if (p >= lo && p + 4 <= hi) {
+      *(uint32_t*)(base + p) = w;
+    } else if (p < hi && p + 4 > lo) {
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (p + j >= lo && p + j < hi) base[p + j] = (uint8_t)(w >> (8 * j));
+    }
+  }
 }
 
 __device__ __forceinline__ uint32_t frame_len(uint64_t total, uint64_t frame_bytes, uint64_t f) {
@@ -502,56 +521,31 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t* __restric
 // bit 7-(i&7) of byte end-1-(i>>3), and the 8 bytes at the start of the stream
 // region are zero.
 //
-// As in the decoder, global memory is touched in whole aligned 32-byte blocks
-// moved by two lanes per stream: a round stages one input block per stream in
-// LDS (the next one is already in flight in registers), every lane encodes its
-// 32 bytes into a 4-block output ring, and the blocks that filled up (at most
-// two per round, 12 bits per symbol) are stored.
-constexpr uint32_t kNoBlock = 0xffffffffu;
+// Every lane reads its slice in aligned 32-byte blocks straight into registers
+// (the next block is always in flight) and collects its output in a 128-byte
+// LDS ring, from which whole aligned 32-byte blocks are stored.  The LDS table
+// holds (code << 20) | len per symbol, so two codes are merged with 32-bit
+// operations before one 64-bit shift places them in the accumulator.
 constexpr uint32_t kEncBlk = 32;
-constexpr uint32_t kEncInDw = kEncBlk / 4 + 1;       // input row stride (dwords)
-constexpr uint32_t kEncRing = 4 * kEncBlk;           // output ring bytes per stream
-constexpr uint32_t kEncOutDw = kEncRing / 4 + 1;     // output row stride (dwords)
-
-// Stores one 32-byte block per stream from an output ring; only bytes inside
-// [rlo, rhi) of the stream (offsets from obase) are written.
-template <uint32_t RING_BYTES, uint32_t STRIDE_DW>
-__device__ __forceinline__ void store_blocks(const uint32_t* ring, uint8_t* obase,
-                                             const uint32_t* rlo, const uint32_t* rhi,
-                                             uint32_t flush, uint32_t lane) {
-#pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    const uint32_t r = 32 * i + (lane >> 1);
-    const uint32_t c = lane & 1;
-    const uint32_t fb = __shfl(flush, r, 64);
-    if (fb == kNoBlock) continue;
-    const uint32_t lo = rlo[r], hi = rhi[r];
-    const uint32_t a = fb + 16 * c;  // chunk [a, a+16)
-    const uint32_t* src = ring + r * STRIDE_DW + ((a & (RING_BYTES - 1)) >> 2);
-    if (a >= lo && a + 16 <= hi) {
-      *(uint4*)(obase + a) = make_uint4(src[0], src[1], src[2], src[3]);
-    } else if (a < hi && a + 16 > lo) {
-      for (uint32_t j = 0; j < 16; ++j) {
-        const uint32_t p = a + j;
-        if (p >= lo && p < hi) obase[p] = (uint8_t)(src[j >> 2] >> (8 * (j & 3)));
-      }
-    }
-  }
-}
+constexpr uint32_t kEncRing = 4 * kEncBlk;        // output ring bytes per stream
+constexpr uint32_t kEncOutDw = kEncRing / 4 + 1;  // output row stride (dwords)
+constexpr uint32_t kEncGroup = 4;                 // input blocks loaded at once per lane
 
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     const FrameCode* __restrict__ code, const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
-  __shared__ uint16_t enc[256];
-  __shared__ uint32_t iring[64 * kEncInDw];
+  __shared__ uint32_t enc[256];
   __shared__ uint32_t oring[64 * kEncOutDw];
-  __shared__ uint32_t ilo[64], ihi[64], olo[64], ohi[64];
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
+  STAMP_DECL();
   const FrameCode& fc = code[f];
-  for (uint32_t i = lane; i < 256; i += 64) enc[i] = fc.enc[i];
+  for (uint32_t i = lane; i < 256; i += 64) {
+    const uint32_t e = fc.enc[i];
+    enc[i] = ((e >> 4) << 20) | (e & 15);
+  }
 
   const uint64_t off = comp_off[f];
   const uint32_t size = comp_size[f];
@@ -565,161 +559,160 @@ __global__ __launch_bounds__(64) void encode_kernel(
   if (lane < 4) out[lane] = (uint8_t)(n >> (8 * lane));
   for (uint32_t i = lane; i < hdr_len; i += 64) out[4 + i] = fc.hdr[i];
   if (lane < K - 1) store_u32u(out + 4 + hdr_len + 4 * lane, stream_end[f * 64 + lane]);
+  wave_sync();  // enc[] complete
+  STAMP(0);  // table + header
+  if (lane >= K) return;
 
-  // input rows: offsets from ibase, the 32-byte block holding the frame's
-  // first raw byte; output rows: offsets from obase likewise
+  // input: offsets from ibase, the 32-byte block holding the frame's first raw
+  // byte; output: offsets from obase likewise (pointer arithmetic keeps both in
+  // the global address space)
   const uint8_t* const frame_in = raw + f * frame_bytes;
-  const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);  // keeps the address space
+  const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);
   uint8_t* const obase = out - ((uintptr_t)out & 31);
-  Slice s;
-  s.begin = 0;
-  s.size = 0;
-  uint32_t r_lo = 0, r_hi = 0;
-  if (lane < K) {
-    s = slice_of(n, K, lane);
-    const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
-    r_hi = area + stream_end[f * 64 + lane];
-    r_lo = area + (lane ? stream_end[f * 64 + lane - 1] : 0);
-  }
+  const Slice s = slice_of(n, K, lane);
+  const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
+  const uint32_t r_hi = area + stream_end[f * 64 + lane];
+  const uint32_t r_lo = area + (lane ? stream_end[f * 64 + lane - 1] : 0);
   const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
   const uint32_t in_hi = in_lo + s.size;
-  ilo[lane] = in_lo;
-  ihi[lane] = in_hi;
-  olo[lane] = r_lo;
-  ohi[lane] = r_hi;
-  wave_sync();
 
-  const uint32_t my_rounds = s.size ? ((in_hi + kEncBlk - 1) / kEncBlk - in_lo / kEncBlk) : 0;
-  // cooperative loader: lane handles half c of the block of rows r0, r1
-  const uint32_t c = lane & 1;
-  uint32_t lr[2], lblk[2], lhi[2];
-#pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    lr[i] = 32 * i + (lane >> 1);
-    lblk[i] = (ilo[lr[i]] & ~(kEncBlk - 1)) + 16 * c;
-    lhi[i] = ihi[lr[i]] > ilo[lr[i]] ? ihi[lr[i]] : 0;  // empty slice: never load
-  }
-  uint4 pre[2];
-#pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    pre[i] = make_uint4(0, 0, 0, 0);
-    if (lblk[i] - 16 * c < lhi[i]) pre[i] = *(const uint4*)(ibase + lblk[i]);
-  }
-
-  const uint32_t* irow = iring + lane * kEncInDw;
-  uint32_t* orow = oring + lane * kEncOutDw;
-  // bit writer: acc holds nb pending bits MSB first; wp = the (4-byte aligned)
-  // address just above the next dword to write.  If the stream does not end on
-  // a dword boundary the bytes above its end count as already "written".
+  uint32_t* const orow = oring + lane * kEncOutDw;
+  // bit writer: acc holds nb (< 32 between pairs) pending bits MSB first; wp is
+  // the output offset just above the next dword to emit (4-byte aligned).  If
+  // the stream does not end on a dword boundary the bytes above its end count
+  // as already written.
   uint64_t acc = 0;
   uint32_t nb = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
   uint32_t wp = (r_hi + 3) & ~3u;
-  bool nf_live = lane < K;
-  uint32_t nf = (r_hi - 1) & ~(kEncBlk - 1);            // next block to store (descending)
+  uint32_t nf = (r_hi - 1) & ~(kEncBlk - 1);  // next block to store (descending)
   const uint32_t nf_last = r_lo & ~(kEncBlk - 1);
-  bool done = lane >= K;
+  bool nf_live = true;
 
-#define HFZ_EMIT()                                                  \
-  do {                                                              \
-    if (nb >= 32) {                                                 \
-      wp -= 4;                                                      \
-      orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);     \
-      acc <<= 32;                                                   \
-      nb -= 32;                                                     \
-    }                                                               \
+  // Merges two table entries and appends them.  The dword at wp-4 is written
+  // every time (it is simply rewritten until it is complete); wp, acc and nb
+  // advance only when 32 bits have been collected.
+#define HFZ_PAIR(b0, b1)                                                      \
+  do {                                                                        \
+    const uint32_t e0_ = enc[(b0)], e1_ = enc[(b1)];                          \
+    const uint32_t pair_ = (e0_ & 0xfff00000u) | ((e1_ & 0xfff00000u) >> (e0_ & 31)); \
+    acc |= ((uint64_t)pair_ << 32) >> nb;                                     \
+    nb += (e0_ + e1_) & 31;                                                   \
+    orow[((wp - 4) & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);           \
+    wp -= (nb >> 5) << 2;                                                     \
+    acc <<= (nb & 32);                                                        \
+    nb &= 31;                                                                 \
   } while (0)
-#define HFZ_PUT(byte)                                               \
-  do {                                                              \
-    const uint32_t e_ = enc[(byte)];                                \
-    acc |= (uint64_t)(e_ >> 4) << (52 - nb);                        \
-    nb += e_ & 15;                                                  \
+#define HFZ_ONE(b0)                                                           \
+  do {                                                                        \
+    const uint32_t e0_ = enc[(b0)];                                           \
+    acc |= ((uint64_t)(e0_ & 0xfff00000u) << 32) >> nb;                       \
+    nb += e0_ & 31;                                                           \
+    orow[((wp - 4) & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);           \
+    wp -= (nb >> 5) << 2;                                                     \
+    acc <<= (nb & 32);                                                        \
+    nb &= 31;                                                                 \
+  } while (0)
+  // stores the ring block holding output offsets [blk, blk+32); only bytes of
+  // this stream's region [r_lo, r_hi) are written
+#define HFZ_STORE_BLOCK(blk)                                                  \
+  do {                                                                        \
+    const uint32_t* s_ = orow + (((blk) & (kEncRing - 1)) >> 2);              \
+    if ((blk) >= r_lo && (blk) + kEncBlk <= r_hi) {                           \
+      *(uint4*)(obase + (blk)) = make_uint4(s_[0], s_[1], s_[2], s_[3]);      \
+      *(uint4*)(obase + (blk) + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]); \
+    } else {                                                                  \
+      store_block_clipped(obase, (blk), s_, r_lo, r_hi);                      \
+    }                                                                         \
   } while (0)
 
-  for (uint32_t t = 0; __any(!done); ++t) {
-    // stage block t, start loading block t+1
+  // The slice is read in groups of kEncGroup aligned 32-byte blocks; the loads
+  // of the next group are issued before the current one is encoded, so about
+  // 2*kEncGroup*32 bytes per lane are in flight, which is what it takes to
+  // cover HBM latency at this occupancy.  Addresses past the slice are clamped
+  // to its last block (the data is ignored).
+  const uint32_t nblk = s.size ? ((in_hi + kEncBlk - 1) / kEncBlk - in_lo / kEncBlk) : 0;
+  const uint32_t first_blk = in_lo & ~(kEncBlk - 1);
+  const uint32_t last_blk = nblk ? first_blk + kEncBlk * (nblk - 1) : first_blk;
+  uint4 cur[2 * kEncGroup], nxt[2 * kEncGroup];
+#define HFZ_LOAD_GROUP(dst, g)                                                \
+  do {                                                                        \
+    _Pragma("unroll") for (uint32_t q_ = 0; q_ < kEncGroup; ++q_) {           \
+      uint32_t a_ = first_blk + kEncBlk * ((g) * kEncGroup + q_);             \
+      a_ = a_ < last_blk ? a_ : last_blk;                                     \
+      dst[2 * q_] = *(const uint4*)(ibase + a_);                              \
+      dst[2 * q_ + 1] = *(const uint4*)(ibase + a_ + 16);                     \
+    }                                                                         \
+  } while (0)
+  const uint32_t ngroups = (nblk + kEncGroup - 1) / kEncGroup;
+  if (ngroups) HFZ_LOAD_GROUP(nxt, 0);
+  STAMP(1);  // setup
+  for (uint32_t g = 0; g < ngroups; ++g) {
 #pragma unroll
-    for (uint32_t i = 0; i < 2; ++i) {
-      uint32_t* dst = iring + lr[i] * kEncInDw + 4 * c;
-      dst[0] = pre[i].x;
-      dst[1] = pre[i].y;
-      dst[2] = pre[i].z;
-      dst[3] = pre[i].w;
-    }
-    wave_sync();
+    for (uint32_t q = 0; q < 2 * kEncGroup; ++q) cur[q] = nxt[q];
+    if (g + 1 < ngroups) HFZ_LOAD_GROUP(nxt, g + 1);
 #pragma unroll
-    for (uint32_t i = 0; i < 2; ++i) {
-      lblk[i] += kEncBlk;
-      if (lblk[i] - 16 * c < lhi[i]) pre[i] = *(const uint4*)(ibase + lblk[i]);
-    }
-
-    if (!done) {
-      if (t < my_rounds) {
-        const uint32_t b = (in_lo & ~(kEncBlk - 1)) + kEncBlk * t;
-        if (b >= in_lo && b + kEncBlk <= in_hi) {
+    for (uint32_t q = 0; q < kEncGroup; ++q) {
+      const uint32_t t = g * kEncGroup + q;
+      if (t >= nblk) break;
+      const uint32_t w[8] = {cur[2 * q].x,     cur[2 * q].y,     cur[2 * q].z,     cur[2 * q].w,
+                             cur[2 * q + 1].x, cur[2 * q + 1].y, cur[2 * q + 1].z, cur[2 * q + 1].w};
+      const uint32_t b = first_blk + kEncBlk * t;
+      if (b >= in_lo && b + kEncBlk <= in_hi) {
 #pragma unroll
-          for (uint32_t d = 0; d < kEncBlk / 4; ++d) {
-            const uint32_t w = irow[d];
-            HFZ_PUT(w & 0xff);
-            HFZ_PUT((w >> 8) & 0xff);
-            HFZ_EMIT();
-            HFZ_PUT((w >> 16) & 0xff);
-            HFZ_PUT(w >> 24);
-            HFZ_EMIT();
-          }
-        } else {
-          for (uint32_t j = 0; j < kEncBlk; ++j) {
-            const uint32_t p = b + j;
-            if (p >= in_lo && p < in_hi) {
-              HFZ_PUT((irow[j >> 2] >> (8 * (j & 3))) & 0xff);
-              HFZ_EMIT();
-            }
+        for (uint32_t d = 0; d < kEncBlk / 4; ++d) {
+          HFZ_PAIR(w[d] & 0xff, (w[d] >> 8) & 0xff);
+          HFZ_PAIR((w[d] >> 16) & 0xff, w[d] >> 24);
+        }
+      } else {
+#pragma unroll
+        for (uint32_t d = 0; d < kEncBlk / 4; ++d) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t p = b + 4 * d + j;
+            if (p >= in_lo && p < in_hi) HFZ_ONE((w[d] >> (8 * j)) & 0xff);
           }
         }
       }
-      if (t + 1 >= my_rounds) {
-        // end of stream: pad to a byte, then the 8 zero bytes of slop
-        // (codec/huffman.cpp:770), then the last partial dword
-        nb = (nb + 7) & ~7u;
-        HFZ_EMIT();
-        nb += 32;
-        HFZ_EMIT();
-        nb += 32;
-        HFZ_EMIT();
-        if (nb > 0) {
-          wp -= 4;
-          orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
-          nb = 0;
-        }
-        done = true;
-      }
-    }
-    // store the blocks that are complete (everything at or above wp is written)
-    wave_sync();
+      // store the blocks that are complete (everything at or above wp is final)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      uint32_t flush = kNoBlock;
-      if (nf_live && wp <= nf) {
-        flush = nf;
-        if (nf == nf_last) nf_live = false;
-        nf -= kEncBlk;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (nf_live && wp <= nf) {
+          HFZ_STORE_BLOCK(nf);
+          if (nf == nf_last) nf_live = false;
+          nf -= kEncBlk;
+        }
       }
-      if (__any(flush != kNoBlock))
-        store_blocks<kEncRing, kEncOutDw>(oring, obase, olo, ohi, flush, lane);
     }
-    wave_sync();
   }
-#undef HFZ_EMIT
-#undef HFZ_PUT
-  // the lowest blocks of each stream region (partial, or finished last round)
-  while (__any(nf_live)) {
-    uint32_t flush = kNoBlock;
-    if (nf_live) {
-      flush = nf;
-      if (nf == nf_last) nf_live = false;
-      nf -= kEncBlk;
+#undef HFZ_LOAD_GROUP
+  STAMP(3);  // main loop
+  // end of stream: pad to a byte, then the 8 zero bytes of slop
+  // (codec/huffman.cpp:770), then the last partial dword
+  nb = (nb + 7) & ~7u;
+#pragma unroll
+  for (int z = 0; z < 3; ++z) {
+    if (nb >= 32) {
+      wp -= 4;
+      orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
+      acc <<= 32;
+      nb -= 32;
     }
-    store_blocks<kEncRing, kEncOutDw>(oring, obase, olo, ohi, flush, lane);
+    if (z < 2) nb += 32;
   }
+  if (nb > 0) {
+    wp -= 4;
+    orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
+  }
+  while (nf_live) {
+    HFZ_STORE_BLOCK(nf);
+    if (nf == nf_last) nf_live = false;
+    nf -= kEncBlk;
+  }
+#undef HFZ_PAIR
+#undef HFZ_ONE
+#undef HFZ_STORE_BLOCK
+  STAMP(4);  // tail
+  STAMP_FLUSH(8);
 }
 
 // ---------------------------------------------------------------------------
@@ -1050,7 +1043,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
 #undef HFZ_LOAD_BLOCK
 #undef HFZ_STAGE_BLOCK
   STAMP(7);  // tail
-  STAMP_FLUSH();
+  STAMP_FLUSH(0);
   if (status) {
     const bool any_bad = __any(stream_bad);
     if (lane == 0) status[f] = any_bad ? HFZ_E_CORRUPT : HFZ_OK;

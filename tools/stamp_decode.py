@@ -19,9 +19,12 @@ for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     codec.decompress(batch, out); torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 16)()
     L.hfz_debug_stamps(buf, 1)
-    codec.decompress(batch, out); torch.cuda.synchronize()
+    codec.compress(raw); codec.decompress(batch, out); torch.cuda.synchronize()
     L.hfz_debug_stamps(buf, 1)
     tot = sum(buf[:8]); nf = codec.n_frames
     print("frame_kib", frame_kib, "frames", nf, "cycles/wave %.0f" % (tot / nf),
           " ".join("%s=%.1f%%" % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)))
+    et = sum(buf[8:16])
+    print("  encode cycles/wave %.0f" % (et / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[8 + i] / et)
+          for i, n in enumerate(["table+header", "setup", "-", "main loop", "tail"])))
     print("equal:", bool(torch.equal(out, raw)))
