@@ -269,9 +269,9 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
   HFZ_HIP(mark(0, st));
   HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
   HFZ_HIP(mark(1, st));
-  HFZ_HIP(launch_build_codes(d_hist, nf, d_code, stream));
-  HFZ_HIP(mark(2, st));
-  HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_code, d_send, d_csize, stream));
+  HFZ_HIP(mark(2, st));  // the code is built inside the sizes kernel (table_ms reads 0)
+  HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_hist, d_code, d_send, d_csize,
+                              stream));
   HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
                                d_status, stream));

@@ -56,9 +56,11 @@ void build_frame_code(const uint32_t hist[256], FrameCode* out);
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                      uint64_t n_frames, uint32_t* d_hist, void* stream);
 int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream);
+// d_hist != nullptr: also builds d_code[f] from d_hist[f] (what the batch encoder does);
+// d_hist == nullptr: d_code[f] is given.
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                        uint64_t n_frames, const FrameCode* d_code, uint32_t* d_stream_end,
-                        uint32_t* d_csize, void* stream);
+                        uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
+                        uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
                          int32_t* d_status, void* stream);

@@ -270,16 +270,17 @@ __device__ void introsort_loop(const SortArrays& a, int n, int* stk) {
   }
 }
 
-__global__ __launch_bounds__(64) void code_kernel(const uint32_t* __restrict__ hist,
-                                                  FrameCode* __restrict__ code) {
+// Builds the code of one frame from its histogram (one wave) and writes the
+// FrameCode record; returns the LDS copy of the enc table, (code << 4) | len.
+__device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict__ hist,
+                                                      FrameCode* __restrict__ code, uint64_t f,
+                                                      uint32_t lane) {
   __shared__ uint32_t key[256], key2[256], tcount[256], lcount[256];
   __shared__ uint8_t sym[256], sym2[256];
   __shared__ uint16_t parent[2][256], depthv[2][256], lparent[256], encs[256];
   __shared__ uint32_t hdrw[70];
   __shared__ int stk[3 * 40];
   __shared__ int tree_size_s;
-  const uint64_t f = blockIdx.x;
-  const uint32_t lane = threadIdx.x;
 
   // symbols with a nonzero count, ascending (:342-347)
   const uint4 h4 = *(const uint4*)(hist + f * 256 + 4 * lane);
@@ -429,49 +430,109 @@ __global__ __launch_bounds__(64) void code_kernel(const uint32_t* __restrict__ h
   uint32_t* hdr_out = (uint32_t*)out.hdr;
   for (uint32_t i = lane; i < 69; i += 64) hdr_out[i] = hdrw[i];
   if (lane == 0) out.hdr_len = 4 + nlen + (uint32_t)n;
+  return encs;
+}
+
+__global__ __launch_bounds__(64) void code_kernel(const uint32_t* __restrict__ hist,
+                                                  FrameCode* __restrict__ code) {
+  (void)build_code(hist, code, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
-// K2: coded size of every stream of a frame (codec/huffman.cpp:770-786):
-// size_k = ceil(sum of code lengths over slice k / 8) + 8, then prefix sums.
-__device__ __forceinline__ uint32_t sum_code_len(const uint8_t* p, uint32_t n,
-                                                 const uint8_t* lens) {
-  uint32_t bits = 0, i = 0;
-  while (i < n && ((uintptr_t)(p + i) & 15)) bits += lens[p[i++]];
-  for (; i + 16 <= n; i += 16) {
-    const uint4 v = *(const uint4*)(p + i);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// K2: the frame's code (see build_code) and the coded size of each of its
+// streams (codec/huffman.cpp:770-786): size_k = ceil(sum of code lengths over
+// slice k / 8) + 8, then prefix sums.  Lane k walks slice k in aligned 32-byte
+// blocks, four blocks per group with the next group already in flight.
+constexpr uint32_t kSzGroup = 4;
+
+__device__ __forceinline__ uint32_t sum_code_len(const uint8_t* __restrict__ ibase, uint32_t in_lo,
+                                                 uint32_t in_hi, const uint8_t* lens) {
+  if (in_hi <= in_lo) return 0;
+  const uint32_t first_blk = in_lo & ~31u;
+  const uint32_t nblk = (in_hi + 31) / 32 - in_lo / 32;
+  const uint32_t last_blk = first_blk + 32 * (nblk - 1);
+  const uint32_t ngroups = (nblk + kSzGroup - 1) / kSzGroup;
+  uint4 cur[2 * kSzGroup], nxt[2 * kSzGroup];
+#define HFZ_LOAD_GROUP(dst, g)                                        \
+  do {                                                                \
+    _Pragma("unroll") for (uint32_t q_ = 0; q_ < kSzGroup; ++q_) {    \
+      uint32_t a_ = first_blk + 32 * ((g) * kSzGroup + q_);           \
+      a_ = a_ < last_blk ? a_ : last_blk;                             \
+      dst[2 * q_] = *(const uint4*)(ibase + a_);                      \
+      dst[2 * q_ + 1] = *(const uint4*)(ibase + a_ + 16);             \
+    }                                                                 \
+  } while (0)
+  uint32_t bits = 0;
+  HFZ_LOAD_GROUP(nxt, 0);
+  for (uint32_t g = 0; g < ngroups; ++g) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (uint32_t q = 0; q < 2 * kSzGroup; ++q) cur[q] = nxt[q];
+    if (g + 1 < ngroups) HFZ_LOAD_GROUP(nxt, g + 1);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bits += lens[(w[j] >> (8 * k)) & 0xff];
+    for (uint32_t q = 0; q < kSzGroup; ++q) {
+      const uint32_t t = g * kSzGroup + q;
+      if (t >= nblk) break;
+      const uint32_t w[8] = {cur[2 * q].x,     cur[2 * q].y,     cur[2 * q].z,     cur[2 * q].w,
+                             cur[2 * q + 1].x, cur[2 * q + 1].y, cur[2 * q + 1].z, cur[2 * q + 1].w};
+      const uint32_t b = first_blk + 32 * t;
+      if (b >= in_lo && b + 32 <= in_hi) {
+#pragma unroll
+        for (uint32_t d = 0; d < 8; ++d) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) bits += lens[(w[d] >> (8 * j)) & 0xff];
+        }
+      } else {
+#pragma unroll
+        for (uint32_t d = 0; d < 8; ++d) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t p = b + 4 * d + j;
+            if (p >= in_lo && p < in_hi) bits += lens[(w[d] >> (8 * j)) & 0xff];
+          }
+        }
+      }
     }
   }
-  for (; i < n; ++i) bits += lens[p[i]];
+#undef HFZ_LOAD_GROUP
   return bits;
 }
 
+// build != 0: the kernel first derives the frame's code from hist[f] and writes
+// code[f]; build == 0: code[f] is given (shared-table mode).
 __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __restrict__ raw,
                                                    uint64_t total, uint64_t frame_bytes,
-                                                   const FrameCode* __restrict__ code,
+                                                   const uint32_t* __restrict__ hist,
+                                                   FrameCode* __restrict__ code, uint32_t build,
                                                    uint32_t* __restrict__ stream_end,
                                                    uint32_t* __restrict__ csize) {
   __shared__ uint8_t lens[256];
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
-  const FrameCode& fc = code[f];
-  for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(fc.enc[i] & 15);
-  __syncthreads();
+  uint32_t hdr_len;
+  if (build) {
+    const uint16_t* encs = build_code(hist, code, f, lane);
+    for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(encs[i] & 15);
+    __syncthreads();
+    hdr_len = code[f].hdr_len;  // written by lane 0 above; same wave, after the barrier
+  } else {
+    const FrameCode& fc = code[f];
+    for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(fc.enc[i] & 15);
+    __syncthreads();
+    hdr_len = fc.hdr_len;
+  }
   const uint32_t n = frame_len(total, frame_bytes, f);
   uint32_t bytes = 0;
   if (lane < K) {
     const Slice s = slice_of(n, K, lane);
-    const uint32_t bits = sum_code_len(raw + f * frame_bytes + s.begin, s.size, lens);
+    const uint8_t* const frame_in = raw + f * frame_bytes;
+    const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);
+    const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
+    const uint32_t bits = sum_code_len(ibase, in_lo, in_lo + s.size, lens);
     bytes = (bits + 7) / 8 + kSlop;
   }
   const uint32_t incl = wave_inclusive_scan(bytes, lane);
   if (lane < K) stream_end[f * 64 + lane] = incl;
-  if (lane == K - 1) csize[f] = 4 + fc.hdr_len + 4 * (K - 1) + incl;
+  if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl;
 }
 
 // ---------------------------------------------------------------------------
@@ -1131,12 +1192,13 @@ int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_c
 }
 
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                        uint64_t n_frames, const FrameCode* d_code, uint32_t* d_stream_end,
-                        uint32_t* d_csize, void* stream) {
+                        uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
+                        uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_raw, total, frame_bytes, d_code, d_stream_end, d_csize);
+                     (uint32_t)K, d_raw, total, frame_bytes, d_hist, d_code,
+                     (uint32_t)(d_hist != nullptr), d_stream_end, d_csize);
   return hipGetLastError();
 }
 
