@@ -784,17 +784,22 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // consumed, byte 2 second symbol (0 if none), byte 3 symbol count.
 //
 // Every lane moves its own stream between global memory and LDS in whole,
-// aligned 32-byte blocks (two 16-byte accesses): per stream LDS holds a
-// two-block input ring (plus an 8-byte mirror of its first bytes so that a
-// 12-byte read never wraps) and a linear three-block output row.  A round is
-// kDecRound lookups: it consumes at most 24 input bytes and produces at most
-// 32 output bytes, so one block load (issued when the previous block was
-// staged, into registers) and one block store per round keep up.  Streams of
-// one frame lie n/K bytes apart, so neighbouring lanes never share a cache
-// line anyway; what matters is that each line is moved in few, aligned pieces.
-constexpr uint32_t kDecBlk = 32;     // bytes per staged block
+// aligned blocks: 64-byte input blocks (four 16-byte loads) into a two-block
+// ring (plus an 8-byte mirror of its first bytes so that a 12-byte read never
+// wraps), 32-byte output blocks from a linear three-block row.  Streams of one
+// frame lie n/K bytes apart, so neighbouring lanes never share a cache line
+// anyway; what matters is that each line is moved in few, aligned pieces.
+//
+// The wave works in super-rounds: every lane that has run out of staged input
+// stages its next block (already loaded into registers during the previous
+// super-round) and starts loading the one after it; then lanes run rounds of
+// kDecRound lookups (at most 24 input bytes, at most 32 output bytes, one block
+// store) until all of them have run out again.  All loads of a wave are thus
+// issued together and have a whole super-round (~70 lookups) to arrive.
+constexpr uint32_t kDecInBlk = 64;   // bytes per staged input block
+constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
 constexpr uint32_t kDecRound = 16;   // lookups per round
-constexpr uint32_t kDecInDw = 19;    // input row: 64 B ring + 8 B mirror + 4 B pad
+constexpr uint32_t kDecInDw = 35;    // input row: 128 B ring + 8 B mirror + 4 B pad
 constexpr uint32_t kDecOutDw = 25;   // output row: 96 B + 4 B slack
 
 __global__ __launch_bounds__(64) void decode_kernel(
@@ -930,12 +935,14 @@ __global__ __launch_bounds__(64) void decode_kernel(
   }
   STAMP(1);  // table
 
-  // Input side: offsets are relative to cbase, a 32-byte aligned address 64
-  // bytes below the frame so that look-ahead never goes negative.  Blocks that
-  // start below the 32-byte block holding the first byte of `comp` are never
-  // loaded (a valid stream never needs them).
-  const uint8_t* cbase = in - ((uintptr_t)in & 31) - 64;  // pointer arithmetic: stays a global pointer
-  const int64_t min_off = (int64_t)(((uintptr_t)comp & ~uintptr_t(31)) - (uintptr_t)cbase);
+  // Input side: offsets are relative to cbase, a 64-byte aligned address 256
+  // bytes below the frame, so that the block arithmetic below (up to three
+  // blocks of look-ahead) never goes negative.  Blocks are 64-byte aligned in
+  // absolute terms, so none straddles a page; blocks that start below the
+  // 64-byte block holding the first byte of `comp` are never loaded (a valid
+  // stream never needs them).
+  const uint8_t* cbase = in - ((uintptr_t)in & 63) - 256;  // pointer arithmetic: stays global
+  const int64_t min_off = (int64_t)(((uintptr_t)comp & ~uintptr_t(63)) - (uintptr_t)cbase);
   const uint32_t area_off = (uint32_t)((uintptr_t)in - (uintptr_t)cbase) + hdr_total;
   const uint32_t g_end = area_off + end;  // one past the stream's last byte
   // Output side: offsets relative to obase, the 32-byte block holding the
@@ -955,34 +962,40 @@ __global__ __launch_bounds__(64) void decode_kernel(
   wave_sync();  // table complete; the scratch aliased on the rings is dead
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
-  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+  uint4 pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pre[q] = make_uint4(0, 0, 0, 0);
 #define HFZ_LOAD_BLOCK(blk)                                       \
   do {                                                            \
-    if ((int64_t)(blk) >= min_off) {                              \
-      pre0 = *(const uint4*)(cbase + (blk));                      \
-      pre1 = *(const uint4*)(cbase + (blk) + 16);                 \
+    if ((int64_t)(int32_t)(blk) >= min_off) {                     \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)            \
+        pre[q_] = *(const uint4*)(cbase + (blk) + 16 * q_);       \
     }                                                             \
   } while (0)
-  // writes the registers into ring slot of block `blk`
+  // writes the registers into the ring slot of block `blk`
 #define HFZ_STAGE_BLOCK(blk)                                      \
   do {                                                            \
-    uint32_t* d_ = irow + (((blk) & kDecBlk) >> 2);               \
-    d_[0] = pre0.x; d_[1] = pre0.y; d_[2] = pre0.z; d_[3] = pre0.w; \
-    d_[4] = pre1.x; d_[5] = pre1.y; d_[6] = pre1.z; d_[7] = pre1.w; \
-    if (((blk) & kDecBlk) == 0) {                                 \
-      irow[16] = pre0.x;                                          \
-      irow[17] = pre0.y;                                          \
+    uint32_t* d_ = irow + (((blk) & kDecInBlk) >> 2);             \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {            \
+      d_[4 * q_] = pre[q_].x;                                     \
+      d_[4 * q_ + 1] = pre[q_].y;                                 \
+      d_[4 * q_ + 2] = pre[q_].z;                                 \
+      d_[4 * q_ + 3] = pre[q_].w;                                 \
+    }                                                             \
+    if (((blk) & kDecInBlk) == 0) {                               \
+      irow[32] = pre[0].x;                                        \
+      irow[33] = pre[0].y;                                        \
     }                                                             \
   } while (0)
 
   // prime the ring with the two blocks below the stream end, start the third
-  uint32_t low_blk = (g_end - 1) & ~(kDecBlk - 1);  // lowest block staged so far
+  uint32_t low_blk = (g_end - 1) & ~(kDecInBlk - 1);  // lowest block staged so far
   HFZ_LOAD_BLOCK(low_blk);
   HFZ_STAGE_BLOCK(low_blk);
-  low_blk -= kDecBlk;
+  low_blk -= kDecInBlk;
   HFZ_LOAD_BLOCK(low_blk);
   HFZ_STAGE_BLOCK(low_blk);
-  HFZ_LOAD_BLOCK(low_blk - kDecBlk);
+  HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
   STAMP(2);  // priming
 
   // bit reader (CodeReader, codec/huffman.cpp:502-586): the window is the 8
@@ -1002,7 +1015,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   do {                                                                       \
     ip -= used >> 3;                                                         \
     used &= 7;                                                               \
-    const uint32_t* w_ = irow + ((ip & (2 * kDecBlk - 1)) >> 2);             \
+    const uint32_t* w_ = irow + ((ip & (2 * kDecInBlk - 1)) >> 2);           \
     const uint32_t d0_ = w_[0], d1_ = w_[1], d2_ = w_[2];                    \
     const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, ip & 3);       \
     const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, ip & 3);       \
@@ -1025,71 +1038,76 @@ __global__ __launch_bounds__(64) void decode_kernel(
     }                                                                        \
   } while (0)
 
+  // a lane can run a round when all its windows, [ip-18, ip+8), are staged
+  bool can = false;
   while (__any(left > 0)) {
-    if (left > 0) {
-      // make sure every window of this round, [ip-18, ip+8), is staged
-      ip -= used >> 3;
-      used &= 7;
-      if (ip < area_off) {  // ran below the stream area: corrupt stream
-        stream_bad = true;
-        left = 0;
-      } else if (((ip - 18) & ~(kDecBlk - 1)) < low_blk) {
-        low_blk -= kDecBlk;
-        HFZ_STAGE_BLOCK(low_blk);
-        HFZ_LOAD_BLOCK(low_blk - kDecBlk);
-      }
+    if (left > 0 && ip - 18 < low_blk) {  // out of staged input: next block
+      low_blk -= kDecInBlk;
+      HFZ_STAGE_BLOCK(low_blk);
+      HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
     }
+    can = left > 0;
     STAMP(3);  // staging
-    if (left >= 2 * kDecRound) {
-      // fast round: every lookup may emit two symbols without bounds checks
-      const uint32_t before = wa;
+    while (__any(can)) {
+      if (can) {
+        if (left >= 2 * kDecRound) {
+          // fast round: every lookup may emit two symbols without bounds checks
+          const uint32_t before = wa;
 #pragma unroll
-      for (uint32_t j = 0; j < kDecRound / 4; ++j) {
-        HFZ_WINDOW();
+          for (uint32_t j = 0; j < kDecRound / 4; ++j) {
+            HFZ_WINDOW();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-          orow[wa] = (uint8_t)e;
-          orow[wa + 1] = (uint8_t)(e >> 16);
-          wa += e >> 24;
-          const uint32_t nb = (e >> 8) & 0xff;
-          bitbuf <<= nb;
-          used += nb;
+            for (int t = 0; t < 4; ++t) {
+              const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
+              orow[wa] = (uint8_t)e;
+              orow[wa + 1] = (uint8_t)(e >> 16);
+              wa += e >> 24;
+              const uint32_t nb = (e >> 8) & 0xff;
+              bitbuf <<= nb;
+              used += nb;
+            }
+          }
+          left -= wa - before;
+        } else {
+          // last symbols of the slice; the final one may be the first half of
+          // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
+          for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
+            if ((j & 3) == 0) HFZ_WINDOW();
+            const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
+            uint32_t ns = e >> 24;
+            if (ns > left) ns = 1;
+            orow[wa] = (uint8_t)e;
+            orow[wa + 1] = (uint8_t)(e >> 16);
+            wa += ns;
+            left -= ns;
+            const uint32_t nb = (e >> 8) & 0xff;
+            bitbuf <<= nb;
+            used += nb;
+          }
         }
-      }
-      left -= wa - before;
-    } else if (left > 0) {
-      // last symbols of the slice; the final one may be the first half of a
-      // two-symbol entry (Decode1, codec/huffman.cpp:875-878)
-      for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-        if ((j & 3) == 0) HFZ_WINDOW();
-        const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-        uint32_t ns = e >> 24;
-        if (ns > left) ns = 1;
-        orow[wa] = (uint8_t)e;
-        orow[wa + 1] = (uint8_t)(e >> 16);
-        wa += ns;
-        left -= ns;
-        const uint32_t nb = (e >> 8) & 0xff;
-        bitbuf <<= nb;
-        used += nb;
-      }
-    }
-    STAMP(4);  // lookups
-    // store the block that filled up in this round, if any; after two blocks
-    // move the rest of the row back to its start
-    if (wa >= kDecBlk * (fl + 1)) {
-      HFZ_STORE_BLOCK(fl);
-      ++fl;
-      if (fl == 2) {
+        // store the block that filled up in this round, if any; after two
+        // blocks move the rest of the row back to its start
+        if (wa >= kDecBlk * (fl + 1)) {
+          HFZ_STORE_BLOCK(fl);
+          ++fl;
+          if (fl == 2) {
 #pragma unroll
-        for (uint32_t d = 0; d < kDecOutDw - 16; ++d) orow32[d] = orow32[16 + d];
-        wa -= 2 * kDecBlk;
-        row0 += 2 * kDecBlk;
-        fl = 0;
+            for (uint32_t d = 0; d < kDecOutDw - 16; ++d) orow32[d] = orow32[16 + d];
+            wa -= 2 * kDecBlk;
+            row0 += 2 * kDecBlk;
+            fl = 0;
+          }
+        }
+        ip -= used >> 3;
+        used &= 7;
+        if (ip < area_off) {  // ran below the stream area: corrupt stream
+          stream_bad = true;
+          left = 0;
+        }
+        can = left > 0 && ip - 18 >= low_blk;
       }
     }
-    STAMP(5);  // block store + row shift
+    STAMP(4);  // rounds
   }
   // whatever is left in the row: up to three (partial) blocks
 #pragma unroll

@@ -9,7 +9,7 @@ hfz = importlib.import_module("huffman-avx512_amd")
 hfz.LIB_PATH = os.path.join(ROOT, "tools", "libhfz_stamp.so")
 L = hfz.lib()
 from bench import geometric_cdf
-names = ["header", "table", "priming", "staging", "lookups", "store", "shift", "tail"]
+names = ["header", "table", "priming", "staging", "rounds", "-", "-", "tail"]
 for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     total = 256 << 20
     raw = hfz.generate(geometric_cdf(), 1000, total)
