@@ -780,13 +780,15 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // K4 + K5: decode.  The 4096-entry two-symbol table of Decoder2x
 // (codec/huffman.cpp:644-681) is rebuilt in LDS from the frame header, then
 // lane k decodes stream k (CodeReader + Decode, codec/huffman.cpp:502-586,
-// 683-689, 931-953).  Entry layout (u32): byte 0 first symbol, byte 1 bits
-// consumed, byte 2 second symbol (0 if none), byte 3 symbol count.
+// 683-689, 931-953).  Entry layout (u32): byte 0 bits consumed, byte 1 first
+// symbol, byte 2 second symbol (0 if none), byte 3 eight times the symbol
+// count, so that consuming a code is one 64-bit shift by the entry itself and
+// appending its symbols is one shift by a running bit offset.
 //
 // Every lane moves its own stream between global memory and LDS in whole,
 // aligned blocks: 64-byte input blocks (four 16-byte loads) into a two-block
 // ring (plus an 8-byte mirror of its first bytes so that a 12-byte read never
-// wraps), 32-byte output blocks from a linear three-block row.  Streams of one
+// wraps), 32-byte output blocks from a two-block ring.  Streams of one
 // frame lie n/K bytes apart, so neighbouring lanes never share a cache line
 // anyway; what matters is that each line is moved in few, aligned pieces.
 //
@@ -798,9 +800,9 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // issued together and have a whole super-round (~70 lookups) to arrive.
 constexpr uint32_t kDecInBlk = 64;   // bytes per staged input block
 constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
-constexpr uint32_t kDecRound = 16;   // lookups per round
+constexpr uint32_t kDecRound = 16;   // lookups per round (four windows of four)
 constexpr uint32_t kDecInDw = 35;    // input row: 128 B ring + 8 B mirror + 4 B pad
-constexpr uint32_t kDecOutDw = 25;   // output row: 96 B + 4 B slack
+constexpr uint32_t kDecOutDw = 17;   // output row: 64 B ring + 4 B pad
 
 __global__ __launch_bounds__(64) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   __shared__ uint32_t tab[4096];
   __shared__ uint32_t ringmem[64 * (kDecInDw + kDecOutDw)];
   uint32_t* const iring = ringmem;
-  uint32_t* const obuf = ringmem + 64 * kDecInDw;
+  uint32_t* const obuf_all = ringmem + 64 * kDecInDw;
   // scratch that is only live while the table is built
   uint8_t* const l1tab = (uint8_t*)ringmem;  // first-code length per table index (on iring)
   static_assert(sizeof(uint32_t) * 64 * kDecInDw >= 4096, "l1tab fits in the input rings");
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   const uint8_t* in = comp + off;
   // One round trip brings the whole header (at most 8 + 13 + 256 + 4*63 bytes)
   // into LDS; everything below parses it from there.
-  uint32_t* const hdrw = obuf;  // 192 dwords, dead once the streams start
+  uint32_t* const hdrw = obuf_all;  // 192 dwords, dead once the streams start
   const uint8_t* const hb = (const uint8_t*)hdrw;
 #pragma unroll
   for (uint32_t j = 0; j < 3; ++j) {
@@ -917,12 +919,12 @@ __global__ __launch_bounds__(64) void decode_kernel(
 #pragma unroll 4
     for (uint32_t e = lo + lane; e < hi; e += 64) {
       const uint32_t j = soff[L] + ((e - lo) >> (kMaxCodeLen - L));
-      tab[e] = (uint32_t)syms[j] | ((uint32_t)L << 8) | (1u << 24);
+      tab[e] = (uint32_t)L | ((uint32_t)syms[j] << 8) | (8u << 24);
       l1tab[e] = (uint8_t)L;
     }
   }
   wave_sync();
-  // second symbol where both codes fit in 12 bits.  Byte 0 of an entry and
+  // second symbol where both codes fit in 12 bits.  Byte 1 of an entry and
   // l1tab never change in this pass, so reading another lane's entry while it
   // is being rewritten is safe.
 #pragma unroll 8
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
     const uint32_t rem = (e << L1) & 0xfff;
     const uint32_t L2 = l1tab[rem];
     if (L1 + L2 <= (uint32_t)kMaxCodeLen)
-      tab[e] = (tab[e] & 0xff) | ((L1 + L2) << 8) | ((tab[rem] & 0xff) << 16) | (2u << 24);
+      tab[e] = (L1 + L2) | (tab[e] & 0xff00) | ((tab[rem] & 0xff00) << 8) | (16u << 24);
   }
   STAMP(1);  // table
 
@@ -957,8 +959,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   const uint32_t out_hi = out_lo + s.size;
 
   uint32_t* const irow = iring + lane * kDecInDw;
-  uint32_t* const orow32 = obuf + lane * kDecOutDw;
-  uint8_t* const orow = (uint8_t*)orow32;
+  uint32_t* const orow32 = obuf_all + lane * kDecOutDw;
   wave_sync();  // table complete; the scratch aliased on the rings is dead
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
@@ -1003,11 +1004,14 @@ __global__ __launch_bounds__(64) void decode_kernel(
   uint32_t ip = g_end - 8;
   uint32_t used = 0;
   uint64_t bitbuf = 0;
-  // output: bytes go to orow[wa], wa counts from the start of the row; the row
-  // starts at output offset row0 (32-byte aligned), `fl` blocks of it are stored
-  uint32_t wa = out_lo & (kDecBlk - 1);
-  uint32_t row0 = out_lo & ~(kDecBlk - 1);
-  uint32_t fl = 0;
+  // output: decoded bytes collect in obuf (sh = 8 * their number, < 32 between
+  // lookup pairs); wp is the output offset of the dword being filled.  That
+  // dword is written to the ring after every pair and simply rewritten until it
+  // is complete.  nfb = next 32-byte block to store.
+  uint64_t obuf = 0;
+  uint32_t sh = 8 * (out_lo & 3);  // bytes below the slice start in the first dword
+  uint32_t wp = out_lo & ~3u;
+  uint32_t nfb = out_lo & ~(kDecBlk - 1);
   uint32_t left = s.size;  // symbols still to produce
   bool stream_bad = false;
 
@@ -1021,21 +1025,34 @@ __global__ __launch_bounds__(64) void decode_kernel(
     const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, ip & 3);       \
     bitbuf = (((uint64_t)hi_ << 32) | lo_) << used;                          \
   } while (0)
-  // stores block slot `slot` of the output row (output offset row0 + 32*slot);
-  // only bytes of this stream's slice [out_lo, out_hi) are written
-#define HFZ_STORE_BLOCK(slot)                                                \
+#define HFZ_LOOKUP()                                                         \
   do {                                                                       \
-    const uint32_t a_ = row0 + kDecBlk * (slot);                             \
-    const uint32_t* s_ = orow32 + (kDecBlk / 4) * (slot);                    \
-    if (a_ >= out_lo && a_ + kDecBlk <= out_hi) {                            \
-      *(uint4*)(obase + a_) = make_uint4(s_[0], s_[1], s_[2], s_[3]);        \
-      *(uint4*)(obase + a_ + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]);   \
+    const uint32_t e_ = tab[(uint32_t)(bitbuf >> 52)];                       \
+    obuf |= (uint64_t)((e_ >> 8) & 0xffff) << sh;                            \
+    sh += e_ >> 24;                                                          \
+    bitbuf <<= (e_ & 63);                                                    \
+    used += e_ & 0xff;                                                       \
+  } while (0)
+#define HFZ_DRAIN()                                                          \
+  do {                                                                       \
+    orow32[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;                  \
+    const uint32_t f_ = sh & 32;                                             \
+    obuf >>= f_;                                                             \
+    wp += f_ >> 3;                                                           \
+    sh &= 31;                                                                \
+  } while (0)
+  // stores the ring block holding output offsets [nfb, nfb+32); only bytes of
+  // this stream's slice [out_lo, out_hi) are written
+#define HFZ_STORE_BLOCK()                                                    \
+  do {                                                                       \
+    const uint32_t* s_ = orow32 + ((nfb & kDecBlk) >> 2);                    \
+    if (nfb >= out_lo && nfb + kDecBlk <= out_hi) {                          \
+      *(uint4*)(obase + nfb) = make_uint4(s_[0], s_[1], s_[2], s_[3]);       \
+      *(uint4*)(obase + nfb + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]);  \
     } else {                                                                 \
-      for (uint32_t j_ = 0; j_ < kDecBlk; ++j_) {                            \
-        const uint32_t p_ = a_ + j_;                                         \
-        if (p_ >= out_lo && p_ < out_hi) obase[p_] = orow[kDecBlk * (slot) + j_]; \
-      }                                                                      \
+      store_block_clipped(obase, nfb, s_, out_lo, out_hi);                   \
     }                                                                        \
+    nfb += kDecBlk;                                                          \
   } while (0)
 
   // a lane can run a round when all its windows, [ip-18, ip+8), are staged
@@ -1052,52 +1069,40 @@ __global__ __launch_bounds__(64) void decode_kernel(
       if (can) {
         if (left >= 2 * kDecRound) {
           // fast round: every lookup may emit two symbols without bounds checks
-          const uint32_t before = wa;
+          const uint32_t before = 8 * wp + sh;
 #pragma unroll
           for (uint32_t j = 0; j < kDecRound / 4; ++j) {
             HFZ_WINDOW();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-              orow[wa] = (uint8_t)e;
-              orow[wa + 1] = (uint8_t)(e >> 16);
-              wa += e >> 24;
-              const uint32_t nb = (e >> 8) & 0xff;
-              bitbuf <<= nb;
-              used += nb;
-            }
+            HFZ_LOOKUP();
+            HFZ_LOOKUP();
+            HFZ_DRAIN();
+            HFZ_LOOKUP();
+            HFZ_LOOKUP();
+            HFZ_DRAIN();
           }
-          left -= wa - before;
+          left -= (8 * wp + sh - before) >> 3;
         } else {
           // last symbols of the slice; the final one may be the first half of
           // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
             if ((j & 3) == 0) HFZ_WINDOW();
             const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
-            uint32_t ns = e >> 24;
-            if (ns > left) ns = 1;
-            orow[wa] = (uint8_t)e;
-            orow[wa + 1] = (uint8_t)(e >> 16);
-            wa += ns;
+            uint32_t ns = e >> 27;
+            uint32_t pair = (e >> 8) & 0xffff;
+            if (ns > left) {
+              ns = 1;
+              pair &= 0xff;
+            }
+            obuf |= (uint64_t)pair << sh;
+            sh += 8 * ns;
             left -= ns;
-            const uint32_t nb = (e >> 8) & 0xff;
-            bitbuf <<= nb;
-            used += nb;
+            bitbuf <<= (e & 63);
+            used += e & 0xff;
+            HFZ_DRAIN();
           }
         }
-        // store the block that filled up in this round, if any; after two
-        // blocks move the rest of the row back to its start
-        if (wa >= kDecBlk * (fl + 1)) {
-          HFZ_STORE_BLOCK(fl);
-          ++fl;
-          if (fl == 2) {
-#pragma unroll
-            for (uint32_t d = 0; d < kDecOutDw - 16; ++d) orow32[d] = orow32[16 + d];
-            wa -= 2 * kDecBlk;
-            row0 += 2 * kDecBlk;
-            fl = 0;
-          }
-        }
+        // store the block that filled up in this round, if any
+        if (wp >= nfb + kDecBlk) HFZ_STORE_BLOCK();
         ip -= used >> 3;
         used &= 7;
         if (ip < area_off) {  // ran below the stream area: corrupt stream
@@ -1109,15 +1114,15 @@ __global__ __launch_bounds__(64) void decode_kernel(
     }
     STAMP(4);  // rounds
   }
-  // whatever is left in the row: up to three (partial) blocks
+  // the last partial dword, then what is left in the ring: up to two blocks
+  orow32[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;
 #pragma unroll
-  for (int pass = 0; pass < 3; ++pass) {
-    if (wa > kDecBlk * fl) {
-      HFZ_STORE_BLOCK(fl);
-      ++fl;
-    }
+  for (int pass = 0; pass < 2; ++pass) {
+    if (nfb < out_hi) HFZ_STORE_BLOCK();
   }
 #undef HFZ_WINDOW
+#undef HFZ_LOOKUP
+#undef HFZ_DRAIN
 #undef HFZ_STORE_BLOCK
 #undef HFZ_LOAD_BLOCK
 #undef HFZ_STAGE_BLOCK
