@@ -26,14 +26,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 
-def geometric_cdf():
-    """P(i) = 0.8^i * 0.2 (the biased source of codec/huffman_benchmark.cpp:27-36)
-    as exact integer thresholds floor(2^32 * P(X <= j))."""
-    q = [min(((5 ** (j + 1) - 4 ** (j + 1)) << 32) // 5 ** (j + 1), 0xFFFFFFFF) for j in range(256)]
-    q[255] = 0xFFFFFFFF
-    return np.array(q, dtype=np.uint32)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,7 +33,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="K, streams per frame")
     ap.add_argument("--total-mib", type=int, default=256, help="raw MiB per GPU per step")
-    ap.add_argument("--frame-kib", type=int, default=64, help="raw KiB per frame")
+    ap.add_argument("--frame-kib", type=int, default=256, help="raw KiB per frame")
+    ap.add_argument("--source", choices=("biased", "enwik"), default="biased",
+                    help="biased: P(i)=0.8^i*0.2 (reference benchmark); enwik: wiki-text-like table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
@@ -68,7 +62,7 @@ def main():
     K = args.streams
     total = args.total_mib << 20
     frame_bytes = args.frame_kib << 10
-    cdf = geometric_cdf()
+    cdf = hfz.distributions.SOURCES[args.source]()
     raw = hfz.generate(cdf, 1000 + rank, total, device=dev)
     codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -124,9 +118,15 @@ def main():
     dom = max(("hist", "sizes", "encode", "decode"), key=lambda k: kt[k + "_ms"])
     achieved = alg_bytes[dom] / (kt[dom + "_ms"] * 1e-3) / 1e9 if kt[dom + "_ms"] > 0 else 0.0
     traffic = None
-    try:
+    try:  # PMC passes are separate rocprofv3 runs; use them only for the same workload
         with open(args.traffic_json) as f:
-            traffic = json.load(f).get(dom + "_kernel")
+            prof = json.load(f)
+        pc = (prof.get("bench_line") or {}).get("config", {})
+        same = all(pc.get(k) == v for k, v in (("streams", K), ("raw_mib_per_gpu", args.total_mib),
+                                               ("frame_kib", args.frame_kib),
+                                               ("source", args.source)))
+        if same:
+            traffic = prof.get(dom + "_kernel")
     except (OSError, ValueError):
         pass
     enc_ms = sum(kt[k + "_ms"] for k in ("hist", "table", "sizes", "place", "encode"))
@@ -141,8 +141,11 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "1xMI355X-class, %d-stream encode+decode, %d MiB biased-geometric "
-                               "synthetic per GPU, LDS tables" % (K, args.total_mib),
+        "config": {"workload": "%d-stream encode+decode, %d MiB %s synthetic per GPU, "
+                               "per-frame tables in LDS" % (
+                                   K, args.total_mib,
+                                   "biased-geometric" if args.source == "biased" else "enwik8-like"),
+                   "source": args.source,
                    "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
                    "frames_per_gpu": codec.n_frames, "compressed_over_raw": round(C / N, 4),
                    "layout": "packed"},

@@ -13,6 +13,8 @@ import os
 
 import numpy as np
 
+from . import distributions  # noqa: F401  (integer-only synthetic sources)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhfz.so")
 

@@ -46,15 +46,14 @@ CASE_FILES = (
 )
 
 
-def geometric_cdf(p_num=1, p_den=5):
-    """cdf[j] = floor(2^32 * (1 - (1-p)^(j+1))) for P(i) = (1-p)^i * p, exact
-    integer arithmetic (p = p_num/p_den); the benchmark's biased source
-    (codec/huffman_benchmark.cpp:27-36 uses p = 0.2) without floating point."""
-    q_num, q_den = p_den - p_num, p_den
-    cdf = np.zeros(256, dtype=np.uint32)
-    for j in range(256):
-        a, b = q_num ** (j + 1), q_den ** (j + 1)
-        v = ((b - a) << 32) // b
-        cdf[j] = min(v, 0xFFFFFFFF)
-    cdf[255] = 0xFFFFFFFF
-    return cdf
+def _dist():
+    import importlib
+    return importlib.import_module("huffman-avx512_amd").distributions
+
+
+def geometric_cdf():
+    return _dist().geometric_cdf()
+
+
+def enwik_like_cdf():
+    return _dist().enwik_like_cdf()

@@ -307,3 +307,22 @@ def test_reference_style_typed_suite_cpp(torch_cuda):
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 failed" in out.stdout
+
+
+def test_enwik_like_source_32_streams(torch_cuda):
+    # the 32-stream format on wiki-text-like data: every frame equals the oracle's
+    from helpers import enwik_like_cdf
+    torch = torch_cuda
+    K, total, frame_bytes = 32, (1 << 20) + 4321, 128 << 10
+    raw = hfz.generate(enwik_like_cdf(), 31337, total)
+    host = raw.cpu().numpy().tobytes()
+    assert host == oracle.generate(enwik_like_cdf(), 31337, total).tobytes()
+    codec = hfz.BatchCodec(K, total, frame_bytes)
+    batch = codec.compress(raw)
+    out = codec.decompress(batch)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == host
+    for i in range(codec.n_frames):
+        assert batch.frame_bytes_host(i) == oracle.compress(K, host[i * frame_bytes:(i + 1) * frame_bytes]), i
+    ratio = batch.compressed_bytes() / total
+    assert 0.63 < ratio < 0.67  # order-0 entropy of the table is 5.1 bits/byte
