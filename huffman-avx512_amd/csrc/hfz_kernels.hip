@@ -803,19 +803,40 @@ constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
 constexpr uint32_t kDecRound = 16;   // lookups per round (four windows of four)
 constexpr uint32_t kDecInDw = 35;    // input row: 128 B ring + 8 B mirror + 4 B pad
 constexpr uint32_t kDecOutDw = 17;   // output row: 64 B ring + 4 B pad
+#ifndef HFZ_DEC_TAB_BITS
+#define HFZ_DEC_TAB_BITS 12
+#endif
+// With kDecTabBits = 11 the lookup table is indexed by the next 11 bits, not 12: it is half the size
+// (8 KiB), which is what bounds the number of resident waves per CU.  Codes of
+// up to 11 bits, and pairs of codes of up to 11 bits together, resolve in one
+// lookup.  12-bit codes come in sibling pairs that share an 11-bit prefix (the
+// code is complete and they are the numerically last codes), so their entry
+// holds both symbols and the 12th bit picks one (kDecEsc entries).
+constexpr uint32_t kDecTabBits = HFZ_DEC_TAB_BITS;
+constexpr uint32_t kDecEsc = 0x80000000u;
+
+// Entry layout: byte 0 = bits consumed, byte 1 = first symbol, byte 2 = second
+// symbol (0 if none), byte 3 = 8 * number of symbols.  An escape entry has
+// kDecEsc set and the two sibling symbols in bytes 1 and 2; this turns it into
+// a plain one-symbol entry given the window it was looked up with.
+__device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) {
+  const uint32_t sel = (uint32_t)(bitbuf >> (63 - kDecTabBits)) & 1;
+  const uint32_t sym = (e >> (8 + 8 * sel)) & 0xff;
+  return (uint32_t)kMaxCodeLen | (sym << 8) | (8u << 24);
+}
 
 __global__ __launch_bounds__(64) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
-  __shared__ uint32_t tab[4096];
+  __shared__ uint32_t tab[1u << kDecTabBits];
   __shared__ uint32_t ringmem[64 * (kDecInDw + kDecOutDw)];
   uint32_t* const iring = ringmem;
   uint32_t* const obuf_all = ringmem + 64 * kDecInDw;
   // scratch that is only live while the table is built
   uint8_t* const l1tab = (uint8_t*)ringmem;  // first-code length per table index (on iring)
-  static_assert(sizeof(uint32_t) * 64 * kDecInDw >= 4096, "l1tab fits in the input rings");
+  static_assert(sizeof(uint32_t) * 64 * kDecInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
   static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
@@ -911,28 +932,40 @@ __global__ __launch_bounds__(64) void decode_kernel(
   }
   STAMP(0);  // header
 
-  // single-symbol entries, one code-length class at a time
+  // single-symbol entries, one code-length class at a time; table indices are
+  // the top kDecTabBits bits of the left-aligned 12-bit code space
+  constexpr uint32_t kTabShift = (uint32_t)kMaxCodeLen - kDecTabBits;
+  static_assert(kTabShift <= 1, "escape entries cover one bit");
 #pragma unroll
-  for (int L = 0; L <= kMaxCodeLen; ++L) {
+  for (uint32_t L = 0; L <= kDecTabBits; ++L) {
     if (cnt[L] == 0) continue;
-    const uint32_t lo = fcode[L], hi = fcode[L + 1];
+    const uint32_t lo = fcode[L] >> kTabShift, hi = fcode[L + 1] >> kTabShift;
 #pragma unroll 4
     for (uint32_t e = lo + lane; e < hi; e += 64) {
-      const uint32_t j = soff[L] + ((e - lo) >> (kMaxCodeLen - L));
-      tab[e] = (uint32_t)L | ((uint32_t)syms[j] << 8) | (8u << 24);
+      const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
+      tab[e] = L | ((uint32_t)syms[j] << 8) | (8u << 24);
       l1tab[e] = (uint8_t)L;
     }
   }
+  if (kTabShift) {  // sibling pairs of 12-bit codes (their count is even: the code is complete)
+    const uint32_t lo = fcode[kMaxCodeLen] >> 1;
+    for (uint32_t e = lo + lane; e < (1u << kDecTabBits); e += 64) {
+      const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
+      tab[e] = kDecEsc | (uint32_t)kMaxCodeLen | ((uint32_t)syms[j] << 8) |
+               ((uint32_t)syms[j + 1] << 16) | (8u << 24);
+      l1tab[e] = (uint8_t)kMaxCodeLen;
+    }
+  }
   wave_sync();
-  // second symbol where both codes fit in 12 bits.  Byte 1 of an entry and
-  // l1tab never change in this pass, so reading another lane's entry while it
-  // is being rewritten is safe.
+  // second symbol where both codes fit in the index bits.  Byte 1 of an entry
+  // and l1tab never change in this pass, so reading another lane's entry while
+  // it is being rewritten is safe.
 #pragma unroll 8
-  for (uint32_t e = lane; e < 4096; e += 64) {
+  for (uint32_t e = lane; e < (1u << kDecTabBits); e += 64) {
     const uint32_t L1 = l1tab[e];
-    const uint32_t rem = (e << L1) & 0xfff;
+    const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
     const uint32_t L2 = l1tab[rem];
-    if (L1 + L2 <= (uint32_t)kMaxCodeLen)
+    if (L1 + L2 <= kDecTabBits)
       tab[e] = (L1 + L2) | (tab[e] & 0xff00) | ((tab[rem] & 0xff00) << 8) | (16u << 24);
   }
   STAMP(1);  // table
@@ -1000,34 +1033,57 @@ __global__ __launch_bounds__(64) void decode_kernel(
   STAMP(2);  // priming
 
   // bit reader (CodeReader, codec/huffman.cpp:502-586): the window is the 8
-  // bytes at ip; `used` bits of it are consumed.  bitbuf = window << used.
+  // bytes at ip, of which `used` (< 8 between windows) bits are consumed;
+  // bitbuf = window << used.  `below` holds the 8 bytes under the window, read
+  // from the ring a whole window (four lookups) before they are needed, so the
+  // refill is two shifts and an OR and no LDS read sits on the lookup chain:
+  // after consuming c more bits, the next window is
+  // (bitbuf << c) | (below >> (64 - used - c)).
   uint32_t ip = g_end - 8;
   uint32_t used = 0;
-  uint64_t bitbuf = 0;
+  uint64_t bitbuf = 0, below = 0;
+#define HFZ_READ8(dst, pos)                                                  \
+  do {                                                                       \
+    const uint32_t p_ = (pos);                                               \
+    const uint32_t* w_ = irow + ((p_ & (2 * kDecInBlk - 1)) >> 2);           \
+    const uint32_t d0_ = w_[0], d1_ = w_[1], d2_ = w_[2];                    \
+    const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, p_ & 3);       \
+    const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, p_ & 3);       \
+    dst = ((uint64_t)hi_ << 32) | lo_;                                       \
+  } while (0)
+  HFZ_READ8(bitbuf, ip);
+  HFZ_READ8(below, ip - 8);
   // output: decoded bytes collect in obuf (sh = 8 * their number, < 32 between
   // lookup pairs); wp is the output offset of the dword being filled.  That
   // dword is written to the ring after every pair and simply rewritten until it
-  // is complete.  nfb = next 32-byte block to store.
+  // is complete.  nfb = next 32-byte block to leave the ring.  A full block is
+  // read into sb[] at the end of the round that completed it and stored to
+  // memory at the end of the next one, when the LDS reads have long returned.
   uint64_t obuf = 0;
   uint32_t sh = 8 * (out_lo & 3);  // bytes below the slice start in the first dword
   uint32_t wp = out_lo & ~3u;
   uint32_t nfb = out_lo & ~(kDecBlk - 1);
   uint32_t left = s.size;  // symbols still to produce
   bool stream_bad = false;
+  uint32_t sb[8];
+  uint32_t sb_at = 0;
+  bool sb_full = false;
 
-#define HFZ_WINDOW()                                                         \
+  // `used` may be anything below 64 here; with used == 0 the OR would bring in
+  // all of `below`, which only happens when nothing was consumed since the last
+  // refill: callers that can get there use the guarded form.
+#define HFZ_REFILL()                                                         \
   do {                                                                       \
+    bitbuf |= below >> ((64 - used) & 63);                                   \
     ip -= used >> 3;                                                         \
     used &= 7;                                                               \
-    const uint32_t* w_ = irow + ((ip & (2 * kDecInBlk - 1)) >> 2);           \
-    const uint32_t d0_ = w_[0], d1_ = w_[1], d2_ = w_[2];                    \
-    const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, ip & 3);       \
-    const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, ip & 3);       \
-    bitbuf = (((uint64_t)hi_ << 32) | lo_) << used;                          \
+    HFZ_READ8(below, ip - 8);                                                \
   } while (0)
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
-    const uint32_t e_ = tab[(uint32_t)(bitbuf >> 52)];                       \
+    uint32_t e_ = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];             \
+    if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e_ < 0)              \
+      e_ = resolve_escape(e_, bitbuf);                                       \
     obuf |= (uint64_t)((e_ >> 8) & 0xffff) << sh;                            \
     sh += e_ >> 24;                                                          \
     bitbuf <<= (e_ & 63);                                                    \
@@ -1041,24 +1097,31 @@ __global__ __launch_bounds__(64) void decode_kernel(
     wp += f_ >> 3;                                                           \
     sh &= 31;                                                                \
   } while (0)
-  // stores the ring block holding output offsets [nfb, nfb+32); only bytes of
-  // this stream's slice [out_lo, out_hi) are written
-#define HFZ_STORE_BLOCK()                                                    \
+  // moves the ring block holding output offsets [nfb, nfb+32) into sb[]
+#define HFZ_TAKE_BLOCK()                                                     \
   do {                                                                       \
     const uint32_t* s_ = orow32 + ((nfb & kDecBlk) >> 2);                    \
-    if (nfb >= out_lo && nfb + kDecBlk <= out_hi) {                          \
-      *(uint4*)(obase + nfb) = make_uint4(s_[0], s_[1], s_[2], s_[3]);       \
-      *(uint4*)(obase + nfb + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]);  \
-    } else {                                                                 \
-      store_block_clipped(obase, nfb, s_, out_lo, out_hi);                   \
-    }                                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sb[q_] = s_[q_];        \
+    sb_at = nfb;                                                             \
     nfb += kDecBlk;                                                          \
   } while (0)
+  // stores sb[]; only bytes of this stream's slice [out_lo, out_hi) are written
+#define HFZ_STORE_BLOCK()                                                    \
+  do {                                                                       \
+    if (sb_at >= out_lo && sb_at + kDecBlk <= out_hi) {                      \
+      *(uint4*)(obase + sb_at) = make_uint4(sb[0], sb[1], sb[2], sb[3]);     \
+      *(uint4*)(obase + sb_at + 16) = make_uint4(sb[4], sb[5], sb[6], sb[7]); \
+    } else {                                                                 \
+      store_block_clipped(obase, sb_at, sb, out_lo, out_hi);                 \
+    }                                                                        \
+  } while (0)
 
-  // a lane can run a round when all its windows, [ip-18, ip+8), are staged
+  // A round moves ip down by at most 24 bytes and its last refill reads the 8
+  // bytes below that: a lane can run a round when [ip-32, ip) is staged.
+  constexpr uint32_t kReach = 32;
   bool can = false;
   while (__any(left > 0)) {
-    if (left > 0 && ip - 18 < low_blk) {  // out of staged input: next block
+    if (left > 0 && ip - kReach < low_blk) {  // out of staged input: next block
       low_blk -= kDecInBlk;
       HFZ_STAGE_BLOCK(low_blk);
       HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
@@ -1072,21 +1135,21 @@ __global__ __launch_bounds__(64) void decode_kernel(
           const uint32_t before = 8 * wp + sh;
 #pragma unroll
           for (uint32_t j = 0; j < kDecRound / 4; ++j) {
-            HFZ_WINDOW();
             HFZ_LOOKUP();
             HFZ_LOOKUP();
             HFZ_DRAIN();
             HFZ_LOOKUP();
             HFZ_LOOKUP();
             HFZ_DRAIN();
+            HFZ_REFILL();
           }
           left -= (8 * wp + sh - before) >> 3;
         } else {
           // last symbols of the slice; the final one may be the first half of
           // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-            if ((j & 3) == 0) HFZ_WINDOW();
-            const uint32_t e = tab[(uint32_t)(bitbuf >> 52)];
+            uint32_t e = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
+            if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e < 0) e = resolve_escape(e, bitbuf);
             uint32_t ns = e >> 27;
             uint32_t pair = (e >> 8) & 0xffff;
             if (ns > left) {
@@ -1099,28 +1162,36 @@ __global__ __launch_bounds__(64) void decode_kernel(
             bitbuf <<= (e & 63);
             used += e & 0xff;
             HFZ_DRAIN();
+            if ((j & 3) == 3) HFZ_REFILL();
           }
+          if (used >= 8) HFZ_REFILL();
         }
-        // store the block that filled up in this round, if any
-        if (wp >= nfb + kDecBlk) HFZ_STORE_BLOCK();
-        ip -= used >> 3;
-        used &= 7;
+        // last round's block goes to memory, the one this round filled is read
+        if (sb_full) HFZ_STORE_BLOCK();
+        sb_full = wp >= nfb + kDecBlk;
+        if (sb_full) HFZ_TAKE_BLOCK();
         if (ip < area_off) {  // ran below the stream area: corrupt stream
           stream_bad = true;
           left = 0;
         }
-        can = left > 0 && ip - 18 >= low_blk;
+        can = left > 0 && ip - kReach >= low_blk;
       }
     }
     STAMP(4);  // rounds
   }
+  if (sb_full) HFZ_STORE_BLOCK();
   // the last partial dword, then what is left in the ring: up to two blocks
   orow32[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    if (nfb < out_hi) HFZ_STORE_BLOCK();
+    if (nfb < out_hi) {
+      HFZ_TAKE_BLOCK();
+      HFZ_STORE_BLOCK();
+    }
   }
-#undef HFZ_WINDOW
+#undef HFZ_READ8
+#undef HFZ_REFILL
+#undef HFZ_TAKE_BLOCK
 #undef HFZ_LOOKUP
 #undef HFZ_DRAIN
 #undef HFZ_STORE_BLOCK

@@ -6,8 +6,9 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
-for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"; do
+SET1=${PMC_SET1:-"SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"}
+SET2=${PMC_SET2:-"SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"}
+for SET in "$SET1" "$SET2"; do
   i=$((i+1))
   timeout -s KILL 180 rocprofv3 --pmc $SET --output-format csv -d "$OUT/p$i" -- \
       python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1 || { tail -5 "$OUT/p$i.log"; exit 2; }
