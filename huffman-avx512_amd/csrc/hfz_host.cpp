@@ -267,11 +267,22 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
 
   HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
   HFZ_HIP(mark(0, st));
-  HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
-  HFZ_HIP(mark(1, st));
-  HFZ_HIP(mark(2, st));  // the code is built inside the sizes kernel (table_ms reads 0)
-  HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_hist, d_code, d_send, d_csize,
-                              stream));
+  if (count_kernel_fits(K, frame_bytes)) {
+    // one pass over the input for the per-stream counts (hist_ms), then code and
+    // stream sizes from those (table_ms); sizes_ms reads 0
+    uint32_t* d_counts = (uint32_t*)(ws + w.counts);
+    HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, d_counts, d_hist, d_send, d_csize,
+                         stream));
+    HFZ_HIP(mark(1, st));
+    HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, d_send, d_csize, stream));
+    HFZ_HIP(mark(2, st));
+  } else {
+    HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+    HFZ_HIP(mark(1, st));
+    HFZ_HIP(mark(2, st));  // the code is built inside the sizes kernel (table_ms reads 0)
+    HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_hist, d_code, d_send, d_csize,
+                                stream));
+  }
   HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
                                d_status, stream));

@@ -29,6 +29,7 @@ struct WorkspaceLayout {
   size_t code;        // FrameCode [n]
   size_t stream_end;  // u32 [n][64]  cumulative stream end offsets (incl. slop)
   size_t csize;       // u32 [n]      frame sizes
+  size_t counts;      // u32 [n][256][32]  per-stream byte counts (count_kernel)
   size_t total;
 };
 
@@ -45,6 +46,8 @@ inline WorkspaceLayout workspace_layout(size_t n) {
   off = align256(off + n * 64 * sizeof(uint32_t));
   w.csize = off;
   off = align256(off + n * sizeof(uint32_t));
+  w.counts = off;
+  off = align256(off + n * 256 * 32 * sizeof(uint32_t));
   w.total = off;
   return w;
 }
@@ -61,6 +64,18 @@ int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_c
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
                         uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+// One pass over the input that yields code (build) and stream sizes; usable when
+// count_kernel_fits(): with more than 32 streams its per-stream counters are 16 bits wide.
+inline bool count_kernel_fits(int K, uint64_t frame_bytes) {
+  return K <= 32 || (frame_bytes + (uint64_t)K - 1) / (uint64_t)K <= 65535;
+}
+// d_counts_out != nullptr: writes the per-stream counters and d_hist_out for
+// launch_code_sizes; == nullptr: d_code[f] is given and the sizes are final.
+int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                 uint64_t n_frames, const FrameCode* d_code, uint32_t* d_counts_out,
+                 uint32_t* d_hist_out, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
+                      FrameCode* d_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
                          int32_t* d_status, void* stream);

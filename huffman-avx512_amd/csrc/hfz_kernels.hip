@@ -270,10 +270,11 @@ __device__ void introsort_loop(const SortArrays& a, int n, int* stk) {
   }
 }
 
-// Builds the code of one frame from its histogram (one wave) and writes the
-// FrameCode record; returns the LDS copy of the enc table, (code << 4) | len.
-__device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict__ hist,
-                                                      FrameCode* __restrict__ code, uint64_t f,
+// Builds the code of one frame from its histogram hist[256] (global or LDS)
+// and writes the FrameCode record; returns the LDS copy of the enc table,
+// (code << 4) | len.  Runs on ONE wave (the barriers inside are wave-level), so
+// a larger workgroup calls it from a single wave and synchronises afterwards.
+__device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, FrameCode* __restrict__ out_p,
                                                       uint32_t lane) {
   __shared__ uint32_t key[256], key2[256], tcount[256], lcount[256];
   __shared__ uint8_t sym[256], sym2[256];
@@ -283,7 +284,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
   __shared__ int tree_size_s;
 
   // symbols with a nonzero count, ascending (:342-347)
-  const uint4 h4 = *(const uint4*)(hist + f * 256 + 4 * lane);
+  const uint4 h4 = *(const uint4*)(hist + 4 * lane);
   const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
   uint32_t nz = 0;
 #pragma unroll
@@ -301,11 +302,11 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
       ++pos;
     }
   }
-  __syncthreads();
+  wave_sync();
 
   const SortArrays arr = {sym, key};
   if (lane == 0 && n > 16) introsort_loop(arr, n, stk);
-  __syncthreads();
+  wave_sync();
   // stable order by descending count = what the final insertion sort leaves
   for (int i = (int)lane; i < n; i += 64) {
     const uint32_t k = key[i];
@@ -317,7 +318,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
     sym2[rank] = sym[i];
     key2[rank] = k;
   }
-  __syncthreads();
+  wave_sync();
 
   // two-queue Huffman merge; records each leaf's and node's parent
   if (lane == 0) {
@@ -340,14 +341,14 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
     tree_size_s = ts;
     if (ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
   }
-  __syncthreads();
+  wave_sync();
   const int ts = tree_size_s;
   if (ts == 0) {
     if (lane == 0 && n == 1) lcount[0] = 1;  // a single symbol: zero-length code
   } else {
     // depth of every internal node by pointer jumping (root = ts-1, depth 0)
     for (int i = (int)lane; i < ts; i += 64) depthv[0][i] = i == ts - 1 ? 0 : 1;
-    __syncthreads();
+    wave_sync();
     int cur = 0;
     for (int it = 0; it < 8; ++it) {
       for (int i = (int)lane; i < ts; i += 64) {
@@ -355,13 +356,13 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
         depthv[cur ^ 1][i] = (uint16_t)(depthv[cur][i] + depthv[cur][p]);
         parent[cur ^ 1][i] = parent[cur][p];
       }
-      __syncthreads();
+      wave_sync();
       cur ^= 1;
     }
     for (int i = (int)lane; i < n; i += 64)
       atomicAdd(&lcount[depthv[cur][lparent[i]] + 1], 1u);
   }
-  __syncthreads();
+  wave_sync();
 
   // LimitCodeLengths (:297-327)
   if (lane == 0 && n > 0) {
@@ -382,7 +383,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
       --kraft;
     }
   }
-  __syncthreads();
+  wave_sync();
 
   // canonical codes in sorted order (ForallCodes, :260-284) and header bytes
   uint32_t lc[kMaxCodeLen + 1];
@@ -412,7 +413,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
   }
   uint8_t* hb = (uint8_t*)hdrw;
   for (uint32_t i = lane; i < 70; i += 64) hdrw[i] = 0;
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {
     hdrw[0] = len_mask;
     uint32_t p = 4;
@@ -421,9 +422,9 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
       if (lc[L]) hb[p++] = (uint8_t)lc[L];  // 256 is stored as 0x00 (:801-806)
   }
   for (int i = (int)lane; i < n; i += 64) hb[4 + nlen + i] = sym2[i];
-  __syncthreads();
+  wave_sync();
 
-  FrameCode& out = code[f];
+  FrameCode& out = *out_p;
   uint32_t* enc_out = (uint32_t*)out.enc;
   const uint32_t* encs32 = (const uint32_t*)encs;
   for (uint32_t i = lane; i < 128; i += 64) enc_out[i] = encs32[i];
@@ -435,7 +436,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* __restrict
 
 __global__ __launch_bounds__(64) void code_kernel(const uint32_t* __restrict__ hist,
                                                   FrameCode* __restrict__ code) {
-  (void)build_code(hist, code, blockIdx.x, threadIdx.x);
+  (void)build_code(hist + (uint64_t)blockIdx.x * 256, code + blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
   const uint32_t lane = threadIdx.x;
   uint32_t hdr_len;
   if (build) {
-    const uint16_t* encs = build_code(hist, code, f, lane);
+    const uint16_t* encs = build_code(hist + f * 256, code + f, lane);
     for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(encs[i] & 15);
     __syncthreads();
     hdr_len = code[f].hdr_len;  // written by lane 0 above; same wave, after the barrier
@@ -533,6 +534,226 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
   const uint32_t incl = wave_inclusive_scan(bytes, lane);
   if (lane < K) stream_end[f * 64 + lane] = incl;
   if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl;
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2 in one pass over the input: per-stream byte counts in LDS, from which
+// come the frame histogram (codec/histogram.cpp:193-201), the canonical code
+// (build_code) and the coded size of every stream as
+// sum over symbols of count_k[sym] * len[sym] (codec/huffman.cpp:770-786) -- the
+// input is read once and no per-byte code-length lookup is needed.
+//
+// One workgroup of 256 threads per frame.  Thread t counts part t / K of
+// stream t % K.  The counters form 256 rows (one per byte value) of 32 words:
+//   K > 32 : word = stream / 2, a 16-bit count per stream (slices of at most
+//            65535 bytes; the launcher falls back to hist_kernel + sizes_kernel
+//            beyond that)
+//   K <= 32: word = stream + K * (part % (32 / K)), a 32-bit count
+// Consecutive lanes count different streams, so the 64 lanes of an LDS atomic
+// always fall on 32 different banks whatever the data looks like.
+constexpr uint32_t kCntThreads = 256;
+constexpr uint32_t kCntBlk = 64;  // bytes per lane per load group
+
+__device__ __forceinline__ void count_range(const uint8_t* __restrict__ ibase, uint32_t lo,
+                                            uint32_t hi, uint32_t* col, uint32_t inc) {
+  if (hi <= lo) return;
+  const uint32_t first_blk = lo & ~(kCntBlk - 1);
+  const uint32_t nblk = (hi + kCntBlk - 1) / kCntBlk - lo / kCntBlk;
+  uint4 cur[4], nxt[4];
+#pragma unroll
+  for (uint32_t q = 0; q < 4; ++q) nxt[q] = *(const uint4*)(ibase + first_blk + 16 * q);
+  for (uint32_t t = 0; t < nblk; ++t) {
+    const uint32_t b = first_blk + kCntBlk * t;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) cur[q] = nxt[q];
+    if (t + 1 < nblk) {
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) nxt[q] = *(const uint4*)(ibase + b + kCntBlk + 16 * q);
+    }
+    const uint32_t w[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y,
+                            cur[1].z, cur[1].w, cur[2].x, cur[2].y, cur[2].z, cur[2].w,
+                            cur[3].x, cur[3].y, cur[3].z, cur[3].w};
+    if (b >= lo && b + kCntBlk <= hi) {
+#pragma unroll
+      for (uint32_t d = 0; d < 16; ++d) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+      }
+    } else {
+#pragma unroll
+      for (uint32_t d = 0; d < 16; ++d) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t p = b + 4 * d + j;
+          if (p >= lo && p < hi) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+        }
+      }
+    }
+  }
+}
+
+// counts_out != null: the counters and the frame histogram go to memory and
+// code_sizes_kernel finishes the job (the code construction has long serial
+// stretches, which want many frames per CU in flight, and this kernel's 33 KiB
+// of LDS allows only four).
+// counts_out == null: code[f] is given (shared-table mode) and the stream sizes
+// are computed right here.  hist_out may be null then.
+__global__ __launch_bounds__(kCntThreads) void count_kernel(
+    uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
+    const FrameCode* __restrict__ code, uint32_t* __restrict__ counts_out,
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ stream_end,
+    uint32_t* __restrict__ csize) {
+  __shared__ __align__(16) uint32_t cnt[256 * 32];
+  __shared__ uint32_t lens4[64];  // code length of symbol s in byte s & 3 of word s >> 2
+  __shared__ uint32_t part_bits[kCntThreads / 64][64];
+  const uint64_t f = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint32_t i = tid; i < 256 * 32; i += kCntThreads) cnt[i] = 0;
+  __syncthreads();
+
+  const uint32_t n = frame_len(total, frame_bytes, f);
+  const bool packed = K > 32;
+  const uint32_t parts = kCntThreads / K;  // >= 4
+  const uint32_t reps = packed ? 1 : 32 / K;
+  {
+    const uint32_t stream = tid % K, part = tid / K;
+    if (part < parts) {
+      const Slice s = slice_of(n, K, stream);
+      const uint32_t chunk = ((s.size + parts - 1) / parts + kCntBlk - 1) & ~(kCntBlk - 1);
+      const uint32_t rel_lo = part * chunk < s.size ? part * chunk : s.size;
+      const uint32_t rel_hi = rel_lo + chunk < s.size ? rel_lo + chunk : s.size;
+      const uint8_t* const frame_in = raw + f * frame_bytes;
+      const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & (kCntBlk - 1));
+      const uint32_t in0 = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
+      const uint32_t colidx = packed ? stream >> 1 : stream + K * (part % reps);
+      const uint32_t inc = packed ? 1u << (16 * (stream & 1)) : 1u;
+      count_range(ibase, in0 + rel_lo, in0 + rel_hi, cnt + colidx, inc);
+    }
+  }
+  __syncthreads();
+
+  // frame histogram: thread t sums row t, starting at a different word per
+  // thread so that the 64 lanes read 32 different banks
+  {
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t c = 0; c < 32; ++c) {
+      const uint32_t w = cnt[tid * 32 + ((c + tid) & 31)];
+      sum += packed ? (w & 0xffff) + (w >> 16) : w;
+    }
+    if (hist_out) hist_out[f * 256 + tid] = sum;
+  }
+  if (counts_out) {
+    uint4* dst = (uint4*)(counts_out + f * (256 * 32));
+    const uint4* src = (const uint4*)cnt;
+    for (uint32_t i = tid; i < 256 * 32 / 4; i += kCntThreads) dst[i] = src[i];
+    return;
+  }
+  if (wave == 0) {
+    const uint16_t* enc = code[f].enc;
+    lens4[lane] = (uint32_t)(enc[4 * lane] & 15) | (uint32_t)(enc[4 * lane + 1] & 15) << 8 |
+                  (uint32_t)(enc[4 * lane + 2] & 15) << 16 | (uint32_t)(enc[4 * lane + 3] & 15) << 24;
+  }
+  __syncthreads();
+
+  // coded bits of stream `lane`: each wave covers a quarter of the symbols
+  {
+    uint32_t bits = 0;
+    if (lane < K) {
+      const uint32_t sh = packed ? 16 * (lane & 1) : 0;
+      const uint32_t c0 = packed ? lane >> 1 : lane;
+      for (uint32_t q = 0; q < 16; ++q) {
+        const uint32_t sym0 = wave * 64 + 4 * q;
+        const uint32_t l4 = lens4[sym0 >> 2];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          uint32_t c;
+          if (packed) {
+            c = (cnt[(sym0 + j) * 32 + c0] >> sh) & 0xffff;
+          } else {
+            c = 0;
+            for (uint32_t r = 0; r < reps; ++r) c += cnt[(sym0 + j) * 32 + c0 + K * r];
+          }
+          bits += c * ((l4 >> (8 * j)) & 0xff);
+        }
+      }
+    }
+    part_bits[wave][lane] = bits;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t bytes = 0;
+    if (lane < K) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < kCntThreads / 64; ++q) bits += part_bits[q][lane];
+      bytes = (bits + 7) / 8 + kSlop;
+    }
+    const uint32_t incl = wave_inclusive_scan(bytes, lane);
+    if (lane < K) stream_end[f * 64 + lane] = incl;
+    if (lane == K - 1) csize[f] = 4 + code[f].hdr_len + 4 * (K - 1) + incl;
+  }
+}
+
+// Second half of the counting path, one wave per frame: the frame's code from
+// its histogram (build_code), then the coded size of every stream from the
+// per-stream counts count_kernel left in memory (same layout as its LDS array).
+// Lane l walks the rows of parity l / 32 and owns counter word l % 32.
+__global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
+                                                        const uint32_t* __restrict__ counts,
+                                                        FrameCode* __restrict__ code,
+                                                        uint32_t* __restrict__ stream_end,
+                                                        uint32_t* __restrict__ csize) {
+  __shared__ uint32_t lens[256];
+  __shared__ uint32_t sums[64];
+  const uint64_t f = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t* rows = counts + f * (256 * 32) + lane;  // word (row l/32, column l%32)
+  // the counters do not depend on the code: start fetching them now
+  constexpr uint32_t kAhead = 8;
+  uint32_t nxt[kAhead];
+#pragma unroll
+  for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * i];
+  const uint16_t* encs = build_code(hist + f * 256, code + f, lane);
+  for (uint32_t i = lane; i < 256; i += 64) lens[i] = encs[i] & 15;
+  sums[lane] = 0;
+  wave_sync();
+  const bool packed = K > 32;
+  const uint32_t reps = packed ? 1 : 32 / K;
+  const uint32_t col = lane & 31, par = lane >> 5;
+  uint32_t acc_lo = 0, acc_hi = 0;
+  for (uint32_t g = 0; g < 128 / kAhead; ++g) {
+    uint32_t cur[kAhead];
+#pragma unroll
+    for (uint32_t i = 0; i < kAhead; ++i) cur[i] = nxt[i];
+    if (g + 1 < 128 / kAhead) {
+#pragma unroll
+      for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * (kAhead * (g + 1) + i)];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kAhead; ++i) {
+      const uint32_t len = lens[2 * (kAhead * g + i) + par];
+      if (packed) {
+        acc_lo += (cur[i] & 0xffff) * len;
+        acc_hi += (cur[i] >> 16) * len;
+      } else {
+        acc_lo += cur[i] * len;
+      }
+    }
+  }
+  if (packed) {
+    atomicAdd(&sums[2 * col], acc_lo);
+    atomicAdd(&sums[2 * col + 1], acc_hi);
+  } else if (col < K * reps) {
+    atomicAdd(&sums[col % K], acc_lo);
+  }
+  wave_sync();
+  uint32_t bytes = 0;
+  if (lane < K) bytes = (sums[lane] + 7) / 8 + kSlop;
+  const uint32_t incl = wave_inclusive_scan(bytes, lane);
+  if (lane < K) stream_end[f * 64 + lane] = incl;
+  // hdr_len was written by lane 0 of this wave inside build_code
+  if (lane == K - 1) csize[f] = 4 + code[f].hdr_len + 4 * (K - 1) + incl;
 }
 
 // ---------------------------------------------------------------------------
@@ -1293,6 +1514,28 @@ int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t fr
   hipLaunchKernelGGL(sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
                      (uint32_t)K, d_raw, total, frame_bytes, d_hist, d_code,
                      (uint32_t)(d_hist != nullptr), d_stream_end, d_csize);
+  return hipGetLastError();
+}
+
+int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
+                 uint64_t n_frames, const FrameCode* d_code, uint32_t* d_counts_out,
+                 uint32_t* d_hist_out, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  if (!count_kernel_fits(K, frame_bytes)) return hipErrorInvalidValue;
+  if (d_counts_out ? d_hist_out == nullptr : d_code == nullptr) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(count_kernel, dim3((uint32_t)n_frames), dim3(kCntThreads), 0,
+                     as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, d_code,
+                     d_counts_out, d_hist_out, d_stream_end, d_csize);
+  return hipGetLastError();
+}
+
+int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
+                      FrameCode* d_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                     (uint32_t)K, d_hist, d_counts, d_code, d_stream_end, d_csize);
   return hipGetLastError();
 }
 
