@@ -35,7 +35,7 @@ EXPORTS = (
     "hfz_histogram", "hfz_build_code_table", "hfz_batch_frames", "hfz_workspace_bytes",
     "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
-    "hfz_frame_code_from_table", "hfz_build_codes_dev",
+    "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
 )
 
 
@@ -123,6 +123,8 @@ def lib():
         L.hfz_build_codes_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_timing_enable.restype = ci
         L.hfz_timing_enable.argtypes = [ci]
+        L.hfz_set_decoder_table_bits.restype = ci
+        L.hfz_set_decoder_table_bits.argtypes = [ci]
         L.hfz_timing_read.restype = ci
         L.hfz_timing_read.argtypes = [ctypes.POINTER(BatchTiming)]
         _lib = L
@@ -311,6 +313,11 @@ def shard_frames(n_frames, rank, world):
     q, r = divmod(n_frames, world)
     lo = rank * q + min(rank, r)
     return lo, lo + q + (1 if rank < r else 0)
+
+
+def set_decoder_table_bits(bits=0):
+    """0 = automatic, 11 or 12 = force that build of the decoder's lookup table."""
+    _check(lib().hfz_set_decoder_table_bits(int(bits)), "hfz_set_decoder_table_bits")
 
 
 def timing_enable(on=True):

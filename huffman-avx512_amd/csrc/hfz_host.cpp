@@ -324,6 +324,12 @@ int hfz_frame_code_from_table(const hfz_code_table* t, hfz_frame_code* out) {
   return HFZ_OK;
 }
 
+int hfz_set_decoder_table_bits(int bits) {
+  if (bits != 0 && bits != 11 && bits != 12) return HFZ_E_ARG;
+  g_decoder_table_bits = bits;
+  return HFZ_OK;
+}
+
 int hfz_timing_enable(int on) {
   g_timing.on = on != 0;
   g_timing.enc_calls = g_timing.dec_calls = 0;

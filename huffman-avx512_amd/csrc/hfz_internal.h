@@ -52,6 +52,9 @@ inline WorkspaceLayout workspace_layout(size_t n) {
   return w;
 }
 
+// 0 = choose by frame count, 11 / 12 = forced (hfz_set_decoder_table_bits).
+extern int g_decoder_table_bits;
+
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);
 

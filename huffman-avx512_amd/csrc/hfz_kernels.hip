@@ -1022,18 +1022,18 @@ __global__ __launch_bounds__(64) void encode_kernel(
 constexpr uint32_t kDecInBlk = 64;   // bytes per staged input block
 constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
 constexpr uint32_t kDecRound = 16;   // lookups per round (four windows of four)
-constexpr uint32_t kDecInDw = 35;    // input row: 128 B ring + 8 B mirror + 4 B pad
-constexpr uint32_t kDecOutDw = 17;   // output row: 64 B ring + 4 B pad
-#ifndef HFZ_DEC_TAB_BITS
-#define HFZ_DEC_TAB_BITS 12
-#endif
-// With kDecTabBits = 11 the lookup table is indexed by the next 11 bits, not 12: it is half the size
+constexpr uint32_t kDecInDw = 32;    // input ring per lane: 128 bytes
+constexpr uint32_t kDecOutDw = 16;   // output ring per lane: 64 bytes
+// Both rings are stored transposed, dword d of lane l at [d * 64 + l]: whatever
+// ring positions the lanes are at, an access puts lane l on bank l % 32, so the
+// rings never cause bank conflicts and need no padding.
+// The decoder exists in two builds.  With kDecTabBits = 11 the lookup table is
+// indexed by the next 11 bits, not 12: it is half the size
 // (8 KiB), which is what bounds the number of resident waves per CU.  Codes of
 // up to 11 bits, and pairs of codes of up to 11 bits together, resolve in one
 // lookup.  12-bit codes come in sibling pairs that share an 11-bit prefix (the
 // code is complete and they are the numerically last codes), so their entry
 // holds both symbols and the 12th bit picks one (kDecEsc entries).
-constexpr uint32_t kDecTabBits = HFZ_DEC_TAB_BITS;
 constexpr uint32_t kDecEsc = 0x80000000u;
 
 // Entry layout: byte 0 = bits consumed, byte 1 = first symbol, byte 2 = second
@@ -1041,11 +1041,12 @@ constexpr uint32_t kDecEsc = 0x80000000u;
 // kDecEsc set and the two sibling symbols in bytes 1 and 2; this turns it into
 // a plain one-symbol entry given the window it was looked up with.
 __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) {
-  const uint32_t sel = (uint32_t)(bitbuf >> (63 - kDecTabBits)) & 1;
+  const uint32_t sel = (uint32_t)(bitbuf >> (63 - 11)) & 1;
   const uint32_t sym = (e >> (8 + 8 * sel)) & 0xff;
   return (uint32_t)kMaxCodeLen | (sym << 8) | (8u << 24);
 }
 
+template <uint32_t kDecTabBits>
 __global__ __launch_bounds__(64) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
@@ -1212,8 +1213,8 @@ __global__ __launch_bounds__(64) void decode_kernel(
   const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
   const uint32_t out_hi = out_lo + s.size;
 
-  uint32_t* const irow = iring + lane * kDecInDw;
-  uint32_t* const orow32 = obuf_all + lane * kDecOutDw;
+  uint32_t* const irow = iring + lane;      // dword d of this lane's input ring: irow[64 * d]
+  uint32_t* const orow32 = obuf_all + lane;  // dword d of its output ring: orow32[64 * d]
   wave_sync();  // table complete; the scratch aliased on the rings is dead
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
@@ -1230,16 +1231,12 @@ __global__ __launch_bounds__(64) void decode_kernel(
   // writes the registers into the ring slot of block `blk`
 #define HFZ_STAGE_BLOCK(blk)                                      \
   do {                                                            \
-    uint32_t* d_ = irow + (((blk) & kDecInBlk) >> 2);             \
+    uint32_t* d_ = irow + 64 * (((blk) & kDecInBlk) >> 2);        \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {            \
-      d_[4 * q_] = pre[q_].x;                                     \
-      d_[4 * q_ + 1] = pre[q_].y;                                 \
-      d_[4 * q_ + 2] = pre[q_].z;                                 \
-      d_[4 * q_ + 3] = pre[q_].w;                                 \
-    }                                                             \
-    if (((blk) & kDecInBlk) == 0) {                               \
-      irow[32] = pre[0].x;                                        \
-      irow[33] = pre[0].y;                                        \
+      d_[64 * (4 * q_)] = pre[q_].x;                              \
+      d_[64 * (4 * q_ + 1)] = pre[q_].y;                          \
+      d_[64 * (4 * q_ + 2)] = pre[q_].z;                          \
+      d_[64 * (4 * q_ + 3)] = pre[q_].w;                          \
     }                                                             \
   } while (0)
 
@@ -1266,8 +1263,10 @@ __global__ __launch_bounds__(64) void decode_kernel(
 #define HFZ_READ8(dst, pos)                                                  \
   do {                                                                       \
     const uint32_t p_ = (pos);                                               \
-    const uint32_t* w_ = irow + ((p_ & (2 * kDecInBlk - 1)) >> 2);           \
-    const uint32_t d0_ = w_[0], d1_ = w_[1], d2_ = w_[2];                    \
+    const uint32_t i0_ = (p_ >> 2) & (kDecInDw - 1);                         \
+    const uint32_t d0_ = irow[64 * i0_];                                     \
+    const uint32_t d1_ = irow[64 * ((i0_ + 1) & (kDecInDw - 1))];            \
+    const uint32_t d2_ = irow[64 * ((i0_ + 2) & (kDecInDw - 1))];            \
     const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, p_ & 3);       \
     const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, p_ & 3);       \
     dst = ((uint64_t)hi_ << 32) | lo_;                                       \
@@ -1312,7 +1311,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   } while (0)
 #define HFZ_DRAIN()                                                          \
   do {                                                                       \
-    orow32[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;                  \
+    orow32[64 * ((wp & (2 * kDecBlk - 1)) >> 2)] = (uint32_t)obuf;           \
     const uint32_t f_ = sh & 32;                                             \
     obuf >>= f_;                                                             \
     wp += f_ >> 3;                                                           \
@@ -1321,8 +1320,8 @@ __global__ __launch_bounds__(64) void decode_kernel(
   // moves the ring block holding output offsets [nfb, nfb+32) into sb[]
 #define HFZ_TAKE_BLOCK()                                                     \
   do {                                                                       \
-    const uint32_t* s_ = orow32 + ((nfb & kDecBlk) >> 2);                    \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sb[q_] = s_[q_];        \
+    const uint32_t* s_ = orow32 + 64 * ((nfb & kDecBlk) >> 2);               \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sb[q_] = s_[64 * q_];   \
     sb_at = nfb;                                                             \
     nfb += kDecBlk;                                                          \
   } while (0)
@@ -1402,7 +1401,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
   }
   if (sb_full) HFZ_STORE_BLOCK();
   // the last partial dword, then what is left in the ring: up to two blocks
-  orow32[(wp & (2 * kDecBlk - 1)) >> 2] = (uint32_t)obuf;
+  orow32[64 * ((wp & (2 * kDecBlk - 1)) >> 2)] = (uint32_t)obuf;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (nfb < out_hi) {
@@ -1478,6 +1477,8 @@ __global__ __launch_bounds__(256) void generate_kernel(const uint32_t* __restric
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 }  // namespace
+
+int g_decoder_table_bits = 0;
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -1565,9 +1566,22 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
                   uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(decode_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
-                     frame_bytes, d_status);
+  // 12-bit table (29 KiB of LDS, 5 frames per CU) while that holds every frame
+  // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
+  // costs less than the extra resident waves return.
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const bool wide = g_decoder_table_bits ? g_decoder_table_bits == 12 : n_frames <= (uint64_t)cus * 5;
+  if (wide)
+    hipLaunchKernelGGL(decode_kernel<12>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                       (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
+                       frame_bytes, d_status);
+  else
+    hipLaunchKernelGGL(decode_kernel<11>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                       (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
+                       frame_bytes, d_status);
   return hipGetLastError();
 }
 

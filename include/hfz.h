@@ -167,9 +167,9 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
  * new window.  Has no counterpart in the reference.
  */
 typedef struct hfz_batch_timing {
-  float hist_ms;    /* byte histogram (K1) */
-  float table_ms;   /* canonical code construction */
-  float sizes_ms;   /* per-stream coded sizes (K2) */
+  float hist_ms;    /* input pass: per-stream byte counts (or the plain histogram, K1) */
+  float table_ms;   /* canonical code construction (+ stream sizes from the counts) */
+  float sizes_ms;   /* separate code-length pass (K2); 0 when the counts gave the sizes */
   float place_ms;   /* frame placement (prefix sum) */
   float encode_ms;  /* encode (K3) */
   float decode_ms;  /* table build + decode (K4+K5) */
@@ -178,6 +178,15 @@ typedef struct hfz_batch_timing {
 } hfz_batch_timing;
 int hfz_timing_enable(int on);
 int hfz_timing_read(hfz_batch_timing* out);
+
+/*
+ * The decoder has two builds of its lookup table (the reference has one,
+ * Decoder2x, codec/huffman.cpp:634-704): 12 index bits (16 KiB of LDS per
+ * frame, no escape entries) and 11 index bits (8 KiB, more frames resident per
+ * CU).  bits = 0 (default) picks by the number of frames in the call; 11 or 12
+ * forces one, for tests and tuning.  Decoded bytes are identical.  Process-wide.
+ */
+int hfz_set_decoder_table_bits(int bits);
 
 /*
  * Deterministic integer-only synthetic source, filled on the device:

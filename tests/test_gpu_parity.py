@@ -56,6 +56,32 @@ def test_many_random(torch_cuda):
             assert hfz.decompress(K, comp) == raw, (i, K)
 
 
+@pytest.mark.parametrize("bits", [11, 12])
+def test_both_decoder_table_builds(torch_cuda, bits):
+    # the decoder picks its lookup-table build by frame count; force each one over
+    # every reference case (12-bit codes take the escape entries of the 11-bit build)
+    torch = torch_cuda
+    hfz.set_decoder_table_bits(bits)
+    try:
+        for name in CASE_FILES:
+            raw = load_input(name)
+            for K in KS:
+                assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (bits, name, K)
+        for i, raw in enumerate(many_random()):
+            for K in (1, 4, 32, 64):
+                assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (bits, i, K)
+        # a batch of length-limited frames (every frame has 12-bit codes)
+        K, total, frame = 64, 4 << 20, 64 << 10
+        data = hfz.generate(geometric_cdf(), 5, total)
+        codec = hfz.BatchCodec(K, total, frame)
+        out = codec.decompress(codec.compress(data))
+        torch.cuda.synchronize()
+        assert int(codec.dstatus.abs().sum().item()) == 0
+        assert torch.equal(out, data)
+    finally:
+        hfz.set_decoder_table_bits(0)
+
+
 def test_other_stream_counts(torch_cuda):
     # the AVX-512 paths of the reference also run K = 24, 40, 48
     raw = load_input("long_random.bin")
