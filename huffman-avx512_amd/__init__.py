@@ -26,6 +26,7 @@ HFZ_E_NO_DEVICE = -4
 HFZ_E_HIP = -5
 HFZ_E_TOO_LARGE = -6
 HFZ_E_WORKSPACE = -7
+HFZ_E_CODE_MISMATCH = -8
 MAX_STREAMS = 64
 
 # Every symbol include/hfz.h declares.
@@ -36,6 +37,7 @@ EXPORTS = (
     "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
     "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
+    "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev",
 )
 
 
@@ -111,6 +113,10 @@ def lib():
         L.hfz_compress_batch_dev.argtypes = [ci, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, sz, vp]
         L.hfz_decompress_batch_dev.restype = ci
         L.hfz_decompress_batch_dev.argtypes = [ci, vp, sz, vp, vp, sz, vp, sz, sz, vp, vp]
+        L.hfz_compress_batch_shared_dev.restype = ci
+        L.hfz_compress_batch_shared_dev.argtypes = [ci, vp, sz, sz, vp, vp, sz, sz, vp, vp, vp, vp, sz, vp]
+        L.hfz_decompress_batch_shared_dev.restype = ci
+        L.hfz_decompress_batch_shared_dev.argtypes = [ci, vp, sz, vp, vp, sz, vp, sz, sz, vp, vp]
         L.hfz_histogram_dev.restype = ci
         L.hfz_histogram_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_histogram_batch_dev.restype = ci
@@ -181,6 +187,23 @@ def histogram(raw):
     h = np.zeros(256, dtype=np.uint32)
     _check(lib().hfz_histogram(a.ctypes.data, n, h.ctypes.data), "hfz_histogram")
     return h
+
+
+def histogram_dev(raw):
+    """256 byte counts (numpy uint64) of a device tensor, by hfz_histogram_dev in
+    pieces small enough for its 32-bit counters."""
+    import torch
+    assert raw.is_cuda and raw.dtype == torch.uint8
+    total = np.zeros(256, dtype=np.uint64)
+    d_h = torch.zeros(256, dtype=torch.int32, device=raw.device)
+    piece = 1 << 31
+    st = torch.cuda.current_stream(raw.device).cuda_stream
+    for lo in range(0, raw.numel(), piece):
+        part = raw[lo:lo + piece]
+        _check(lib().hfz_histogram_dev(part.data_ptr(), part.numel(), d_h.data_ptr(), st),
+               "hfz_histogram_dev")
+        total += d_h.cpu().numpy().view(np.uint32).astype(np.uint64)
+    return total
 
 
 def build_code_table(hist):
@@ -281,8 +304,38 @@ class BatchCodec:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def compress(self, raw):
+    def shared_code(self, raw):
+        """One code for the whole batch: device histogram of `raw`, canonical code on
+        the host (as hfz_build_code_table), record copied to the device.  Returns the
+        device tensor to pass to compress(..., code=...).  A multi-GPU job sums the
+        histograms of all ranks before building (see histogram_dev)."""
+        return self.code_from_histogram(histogram_dev(raw))
+
+    def code_from_histogram(self, hist):
+        """hist: 256 counts (any integer width).  Counts beyond 32 bits are scaled
+        down, keeping every symbol that occurs at all."""
+        torch = self.torch
+        h = np.asarray(hist, dtype=np.uint64)
+        shift = 0
+        while int(h.max(initial=0)) >> shift > 0xffffffff:
+            shift += 1
+        if shift:
+            h = np.where(h > 0, np.maximum(h >> np.uint64(shift), 1), 0)
+        fc = frame_code(h.astype(np.uint32))
+        host = torch.frombuffer(bytearray(bytes(fc)), dtype=torch.uint8)
+        return host.to(self.device)
+
+    def compress(self, raw, code=None):
         assert raw.dtype == self.torch.uint8 and raw.numel() == self.total and raw.is_cuda
+        if code is not None:
+            assert code.is_cuda and code.numel() == ctypes.sizeof(FrameCode)
+            _check(lib().hfz_compress_batch_shared_dev(
+                self.K, raw.data_ptr(), self.total, self.frame_bytes, code.data_ptr(),
+                self.comp.data_ptr(), self.comp_cap, self.stride, self.comp_off.data_ptr(),
+                self.comp_size.data_ptr(), self.status.data_ptr(), self.ws.data_ptr(),
+                self.ws_bytes, self._stream()), "hfz_compress_batch_shared_dev")
+            return Batch(self.K, self.comp, self.comp_off, self.comp_size, self.status,
+                         self.total, self.frame_bytes)
         _check(lib().hfz_compress_batch_dev(
             self.K, raw.data_ptr(), self.total, self.frame_bytes, self.comp.data_ptr(),
             self.comp_cap, self.stride, self.comp_off.data_ptr(), self.comp_size.data_ptr(),
@@ -291,15 +344,16 @@ class BatchCodec:
         return Batch(self.K, self.comp, self.comp_off, self.comp_size, self.status, self.total,
                      self.frame_bytes)
 
-    def decompress(self, batch, out=None):
+    def decompress(self, batch, out=None, shared=False):
         torch = self.torch
         if out is None:
             out = torch.empty(max(self.total, 1), dtype=torch.uint8, device=self.device)
-        _check(lib().hfz_decompress_batch_dev(
+        fn = lib().hfz_decompress_batch_shared_dev if shared else lib().hfz_decompress_batch_dev
+        _check(fn(
             self.K, batch.comp.data_ptr(), batch.comp.numel(), batch.comp_off.data_ptr(),
             batch.comp_size.data_ptr(), batch.n_frames, out.data_ptr(), self.total,
             self.frame_bytes, self.dstatus.data_ptr(), self._stream()),
-            "hfz_decompress_batch_dev")
+            "hfz_decompress_batch_shared_dev" if shared else "hfz_decompress_batch_dev")
         return out[: self.total]
 
 

@@ -194,6 +194,7 @@ const char* hfz_strerror(int code) {
     case HFZ_E_HIP: return "HIP call failed";
     case HFZ_E_TOO_LARGE: return "frame too large";
     case HFZ_E_WORKSPACE: return "workspace too small";
+    case HFZ_E_CODE_MISMATCH: return "frame does not carry the shared code";
     default: return "unknown error";
   }
 }
@@ -245,10 +246,16 @@ int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* strea
   return HFZ_OK;
 }
 
-int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
-                           void* d_comp, size_t comp_cap, size_t comp_stride,
-                           uint64_t* d_comp_off, uint32_t* d_comp_size, int32_t* d_status,
-                           void* d_ws, size_t ws_bytes, void* stream) {
+}  // extern "C" (reopened below)
+
+namespace {
+
+// d_shared == nullptr: every frame gets its own code (the reference's
+// CompressMulti<K>); otherwise all frames are coded with *d_shared.
+int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, void* d_comp,
+                   size_t comp_cap, size_t comp_stride, uint64_t* d_comp_off,
+                   uint32_t* d_comp_size, int32_t* d_status, void* d_ws, size_t ws_bytes,
+                   const FrameCode* d_shared, void* stream) {
   if (K < 1 || K > HFZ_MAX_STREAMS || frame_bytes == 0 || !d_comp || !d_comp_off ||
       !d_comp_size || !d_ws || (total && !d_raw))
     return HFZ_E_ARG;
@@ -264,40 +271,44 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
   uint32_t* d_csize = (uint32_t*)(ws + w.csize);
   hipStream_t st = (hipStream_t)stream;
   const uint8_t* raw = (const uint8_t*)d_raw;
+  const bool shared = d_shared != nullptr;
+  const FrameCode* enc_code = shared ? d_shared : d_code;
 
   HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
   HFZ_HIP(mark(0, st));
   if (count_kernel_fits(K, frame_bytes)) {
     // one pass over the input for the per-stream counts (hist_ms), then code and
-    // stream sizes from those (table_ms); sizes_ms reads 0
+    // stream sizes from those (table_ms); sizes_ms reads 0.  With a shared code
+    // the counting kernel turns the counts into sizes itself.
     uint32_t* d_counts = (uint32_t*)(ws + w.counts);
-    HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, d_counts, d_hist, d_send, d_csize,
+    HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, shared ? d_shared : nullptr, shared,
+                         shared ? nullptr : d_counts, shared ? nullptr : d_hist, d_send, d_csize,
                          stream));
     HFZ_HIP(mark(1, st));
-    HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, d_send, d_csize, stream));
+    if (!shared) HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, d_send, d_csize, stream));
     HFZ_HIP(mark(2, st));
   } else {
-    HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+    if (!shared) HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
     HFZ_HIP(mark(1, st));
     HFZ_HIP(mark(2, st));  // the code is built inside the sizes kernel (table_ms reads 0)
-    HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, d_hist, d_code, d_send, d_csize,
-                                stream));
+    HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, shared ? nullptr : d_hist,
+                                shared ? const_cast<FrameCode*>(d_shared) : d_code, shared, d_send,
+                                d_csize, stream));
   }
   HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
                                d_status, stream));
   HFZ_HIP(mark(4, st));
-  HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, d_code, d_send, d_comp_off, d_comp_size,
-                        (uint8_t*)d_comp, comp_cap, stream));
+  HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, enc_code, shared, d_send, d_comp_off,
+                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream));
   HFZ_HIP(mark(5, st));
   g_timing.cur = nullptr;
   return HFZ_OK;
 }
 
-int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
-                             const uint64_t* d_comp_off, const uint32_t* d_comp_size,
-                             size_t n_frames, void* d_raw, size_t raw_cap, size_t frame_bytes,
-                             int32_t* d_status, void* stream) {
+int decompress_batch(int K, const void* d_comp, size_t comp_bytes, const uint64_t* d_comp_off,
+                     const uint32_t* d_comp_size, size_t n_frames, void* d_raw, size_t raw_cap,
+                     size_t frame_bytes, int32_t* d_status, bool shared, void* stream) {
   if (K < 1 || K > HFZ_MAX_STREAMS || !d_comp || !d_comp_off || !d_comp_size || frame_bytes == 0 ||
       (raw_cap && !d_raw))
     return HFZ_E_ARG;
@@ -305,10 +316,47 @@ int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
   HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, kDecEvents));
   HFZ_HIP(mark(0, (hipStream_t)stream));
   HFZ_HIP(launch_decode(K, (const uint8_t*)d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames,
-                        (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
+                        shared, (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
   HFZ_HIP(mark(1, (hipStream_t)stream));
   g_timing.cur = nullptr;
   return HFZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                           void* d_comp, size_t comp_cap, size_t comp_stride,
+                           uint64_t* d_comp_off, uint32_t* d_comp_size, int32_t* d_status,
+                           void* d_ws, size_t ws_bytes, void* stream) {
+  return compress_batch(K, d_raw, total, frame_bytes, d_comp, comp_cap, comp_stride, d_comp_off,
+                        d_comp_size, d_status, d_ws, ws_bytes, nullptr, stream);
+}
+
+int hfz_compress_batch_shared_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                                  const hfz_frame_code* d_code, void* d_comp, size_t comp_cap,
+                                  size_t comp_stride, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                                  int32_t* d_status, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_code) return HFZ_E_ARG;
+  return compress_batch(K, d_raw, total, frame_bytes, d_comp, comp_cap, comp_stride, d_comp_off,
+                        d_comp_size, d_status, d_ws, ws_bytes, (const FrameCode*)d_code, stream);
+}
+
+int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
+                             const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                             size_t n_frames, void* d_raw, size_t raw_cap, size_t frame_bytes,
+                             int32_t* d_status, void* stream) {
+  return decompress_batch(K, d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap,
+                          frame_bytes, d_status, false, stream);
+}
+
+int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes,
+                                    const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                                    size_t n_frames, void* d_raw, size_t raw_cap,
+                                    size_t frame_bytes, int32_t* d_status, void* stream) {
+  return decompress_batch(K, d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap,
+                          frame_bytes, d_status, true, stream);
 }
 
 int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_codes, void* stream) {

@@ -62,32 +62,33 @@ void build_frame_code(const uint32_t hist[256], FrameCode* out);
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                      uint64_t n_frames, uint32_t* d_hist, void* stream);
 int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream);
-// d_hist != nullptr: also builds d_code[f] from d_hist[f] (what the batch encoder does);
-// d_hist == nullptr: d_code[f] is given.
+// d_hist != nullptr: also builds d_code[f] from d_hist[f] (separate-pass encoder);
+// d_hist == nullptr: d_code is given, per frame or (shared_code) one for all frames.
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
-                        uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
 // One pass over the input that yields code (build) and stream sizes; usable when
 // count_kernel_fits(): with more than 32 streams its per-stream counters are 16 bits wide.
 inline bool count_kernel_fits(int K, uint64_t frame_bytes) {
   return K <= 32 || (frame_bytes + (uint64_t)K - 1) / (uint64_t)K <= 65535;
 }
 // d_counts_out != nullptr: writes the per-stream counters and d_hist_out for
-// launch_code_sizes; == nullptr: d_code[f] is given and the sizes are final.
+// launch_code_sizes; == nullptr: d_code is given and the sizes are final.
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                 uint64_t n_frames, const FrameCode* d_code, uint32_t* d_counts_out,
-                 uint32_t* d_hist_out, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+                 uint64_t n_frames, const FrameCode* d_code, bool shared_code,
+                 uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
+                 uint32_t* d_csize, void* stream);
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
                       FrameCode* d_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
                          int32_t* d_status, void* stream);
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                  uint64_t n_frames, const FrameCode* d_code, const uint32_t* d_stream_end,
-                  const uint64_t* d_comp_off, const uint32_t* d_comp_size, uint8_t* d_comp,
-                  uint64_t comp_cap, void* stream);
+                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
+                  const uint32_t* d_stream_end, const uint64_t* d_comp_off,
+                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream);
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
-                  const uint32_t* d_comp_size, uint64_t n_frames, uint8_t* d_raw,
+                  const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
                   uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream);
 int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, uint8_t* d_out,
                     uint64_t n, void* stream);

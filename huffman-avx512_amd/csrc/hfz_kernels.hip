@@ -499,11 +499,13 @@ __device__ __forceinline__ uint32_t sum_code_len(const uint8_t* __restrict__ iba
 }
 
 // build != 0: the kernel first derives the frame's code from hist[f] and writes
-// code[f]; build == 0: code[f] is given (shared-table mode).
+// code[f]; build == 0: code[f * code_step] is given (code_step = 0: one code for
+// every frame).
 __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __restrict__ raw,
                                                    uint64_t total, uint64_t frame_bytes,
                                                    const uint32_t* __restrict__ hist,
                                                    FrameCode* __restrict__ code, uint32_t build,
+                                                   uint32_t code_step,
                                                    uint32_t* __restrict__ stream_end,
                                                    uint32_t* __restrict__ csize) {
   __shared__ uint8_t lens[256];
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
     __syncthreads();
     hdr_len = code[f].hdr_len;  // written by lane 0 above; same wave, after the barrier
   } else {
-    const FrameCode& fc = code[f];
+    const FrameCode& fc = code[f * code_step];
     for (uint32_t i = lane; i < 256; i += 64) lens[i] = (uint8_t)(fc.enc[i] & 15);
     __syncthreads();
     hdr_len = fc.hdr_len;
@@ -596,11 +598,12 @@ __device__ __forceinline__ void count_range(const uint8_t* __restrict__ ibase, u
 // code_sizes_kernel finishes the job (the code construction has long serial
 // stretches, which want many frames per CU in flight, and this kernel's 33 KiB
 // of LDS allows only four).
-// counts_out == null: code[f] is given (shared-table mode) and the stream sizes
+// counts_out == null: code[f * code_step] is given (code_step = 0: one code for
+// every frame) and the stream sizes
 // are computed right here.  hist_out may be null then.
 __global__ __launch_bounds__(kCntThreads) void count_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
-    const FrameCode* __restrict__ code, uint32_t* __restrict__ counts_out,
+    const FrameCode* __restrict__ code, uint32_t code_step, uint32_t* __restrict__ counts_out,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ stream_end,
     uint32_t* __restrict__ csize) {
   __shared__ __align__(16) uint32_t cnt[256 * 32];
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
     return;
   }
   if (wave == 0) {
-    const uint16_t* enc = code[f].enc;
+    const uint16_t* enc = code[f * code_step].enc;
     lens4[lane] = (uint32_t)(enc[4 * lane] & 15) | (uint32_t)(enc[4 * lane + 1] & 15) << 8 |
                   (uint32_t)(enc[4 * lane + 2] & 15) << 16 | (uint32_t)(enc[4 * lane + 3] & 15) << 24;
   }
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
     }
     const uint32_t incl = wave_inclusive_scan(bytes, lane);
     if (lane < K) stream_end[f * 64 + lane] = incl;
-    if (lane == K - 1) csize[f] = 4 + code[f].hdr_len + 4 * (K - 1) + incl;
+    if (lane == K - 1) csize[f] = 4 + code[f * code_step].hdr_len + 4 * (K - 1) + incl;
   }
 }
 
@@ -815,7 +818,8 @@ constexpr uint32_t kEncGroup = 4;                 // input blocks loaded at once
 
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
-    const FrameCode* __restrict__ code, const uint32_t* __restrict__ stream_end,
+    const FrameCode* __restrict__ code, uint32_t code_step,
+    const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
   __shared__ uint32_t enc[256];
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   STAMP_DECL();
-  const FrameCode& fc = code[f];
+  const FrameCode& fc = code[f * code_step];
   for (uint32_t i = lane; i < 256; i += 64) {
     const uint32_t e = fc.enc[i];
     enc[i] = ((e >> 4) << 20) | (e & 15);
@@ -1046,36 +1050,52 @@ __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) 
   return (uint32_t)kMaxCodeLen | (sym << 8) | (8u << 24);
 }
 
-template <uint32_t kDecTabBits>
-__global__ __launch_bounds__(64) void decode_kernel(
+// kWaves = 1: one frame per workgroup, every frame builds its own table.
+// kWaves > 1 (shared-code batches): kWaves frames per workgroup, one wave each;
+// the table is built once, by all waves, from the header of the workgroup's
+// first frame, and a frame whose code section differs from that one is refused
+// (HFZ_E_CODE_MISMATCH) instead of being decoded with the wrong table.
+template <uint32_t kDecTabBits, uint32_t kWaves>
+__global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
-    uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
+    uint64_t n_frames, uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
   __shared__ uint32_t tab[1u << kDecTabBits];
-  __shared__ uint32_t ringmem[64 * (kDecInDw + kDecOutDw)];
-  uint32_t* const iring = ringmem;
-  uint32_t* const obuf_all = ringmem + 64 * kDecInDw;
-  // scratch that is only live while the table is built
-  uint8_t* const l1tab = (uint8_t*)ringmem;  // first-code length per table index (on iring)
+  __shared__ uint32_t ringmem[kWaves * 64 * (kDecInDw + kDecOutDw)];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = kWaves == 1 ? 0 : tid >> 6;
+  uint32_t* const iring = ringmem + wave * 64 * (kDecInDw + kDecOutDw);
+  uint32_t* const obuf_all = iring + 64 * kDecInDw;
+  // scratch that is only live while the table is built (on the first wave's input rings)
+  uint8_t* const l1tab = (uint8_t*)ringmem;
   static_assert(sizeof(uint32_t) * 64 * kDecInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
   static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
-  const uint64_t f = blockIdx.x;
-  const uint32_t lane = threadIdx.x;
+  const uint64_t f = (uint64_t)blockIdx.x * kWaves + wave;
   STAMP_DECL();
+#define HFZ_BARRIER()                 \
+  do {                                \
+    if (kWaves == 1) wave_sync();     \
+    else __syncthreads();             \
+  } while (0)
 
-  const uint64_t off = comp_off[f];
-  const uint32_t size = comp_size[f];
+  // Every wave stages its frame's header: one round trip brings all of it (at
+  // most 8 + 13 + 256 + 4*63 bytes) into LDS; everything below parses it there.
+  const bool present = f < n_frames;
+  uint64_t off = 0;
+  uint32_t size = 0;
+  if (present) {
+    off = comp_off[f];
+    size = comp_size[f];
+  }
   int err = HFZ_OK;
   if (off > comp_bytes || size > comp_bytes - off || size < 8) {
-    if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
-    return;
+    err = HFZ_E_CORRUPT;
+    size = 0;
   }
-  const uint8_t* in = comp + off;
-  // One round trip brings the whole header (at most 8 + 13 + 256 + 4*63 bytes)
-  // into LDS; everything below parses it from there.
+  const uint8_t* in = comp + (err == HFZ_OK ? off : 0);
   uint32_t* const hdrw = obuf_all;  // 192 dwords, dead once the streams start
-  const uint8_t* const hb = (const uint8_t*)hdrw;
 #pragma unroll
   for (uint32_t j = 0; j < 3; ++j) {
     const uint32_t idx = lane + 64 * j;
@@ -1088,22 +1108,18 @@ __global__ __launch_bounds__(64) void decode_kernel(
     }
     hdrw[idx] = v;
   }
-  wave_sync();
-  const uint32_t raw_size = hdrw[0];
-  const uint32_t len_mask = hdrw[1];
-  const uint64_t out_base = f * frame_bytes;
-  uint64_t room = out_base <= raw_cap ? raw_cap - out_base : 0;
-  if (room > frame_bytes) room = frame_bytes;
-  if (raw_size > room) err = HFZ_E_CAPACITY;
-  const uint32_t nlen = __popc(len_mask);
-  if ((len_mask >> (kMaxCodeLen + 1)) != 0 || 8 + nlen > size) err = HFZ_E_CORRUPT;
-  if (err != HFZ_OK) {
-    if (lane == 0 && status) status[f] = err;
-    return;
-  }
+  HFZ_BARRIER();
 
+  // The code section (len_mask, per-length counts, canonical symbol order) is
+  // read from the workgroup's first frame, which is this frame when kWaves = 1.
   // ParseCompressedHeader (codec/huffman.cpp:714-736) + canonical code starts
   // (ForallCodes, codec/huffman.cpp:260-284).
+  const uint32_t* const lead = ringmem + 64 * kDecInDw;
+  const uint8_t* const hb = (const uint8_t*)lead;
+  const uint32_t len_mask = lead[1];
+  const uint32_t nlen = __popc(len_mask);
+  int lead_err = HFZ_OK;
+  if ((len_mask >> (kMaxCodeLen + 1)) != 0) lead_err = HFZ_E_CORRUPT;
   uint32_t cnt[kMaxCodeLen + 1], fcode[kMaxCodeLen + 2], soff[kMaxCodeLen + 1];
   uint32_t cur = 0, nsym = 0, hp = 8;
 #pragma unroll
@@ -1120,36 +1136,61 @@ __global__ __launch_bounds__(64) void decode_kernel(
     nsym += c;
   }
   fcode[kMaxCodeLen + 1] = cur;
-  const uint32_t hdr_total = 8 + nlen + nsym + 4 * (K - 1);
-  if (nsym > 256 || (uint64_t)hdr_total + (uint64_t)kSlop * K > size) err = HFZ_E_CORRUPT;
-  if (nsym == 0 ? raw_size != 0 : cur != (1u << kMaxCodeLen)) err = HFZ_E_CORRUPT;
-  if (err != HFZ_OK) {
-    if (lane == 0 && status) status[f] = err;
+  const uint32_t lead_raw_size = lead[0];
+  if (nsym > 256) lead_err = HFZ_E_CORRUPT;
+  if (nsym == 0 ? lead_raw_size != 0 : cur != (1u << kMaxCodeLen)) lead_err = HFZ_E_CORRUPT;
+  if (lead_err != HFZ_OK) {  // uniform over the workgroup: nobody waits at a barrier below
+    if (lane == 0 && status && present) status[f] = err != HFZ_OK ? err : lead_err;
     return;
   }
   const uint8_t* const syms = hb + 8 + nlen;  // canonical symbol order
 
-  // stream boundaries (codec/huffman.cpp:897-901); lanes >= K get an empty
-  // stream so that they can take part in the cooperative block moves
-  const uint32_t area_size = size - hdr_total;
-  uint32_t end = kSlop, begin = 0;
-  bool bad = false;
-  if (lane < K) {
-    const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
-    if (lane < K - 1) {
-      const uint32_t p = eo + 4 * lane;
-      end = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
-    } else {
-      end = area_size;
+  // this wave's own frame
+  const uint32_t raw_size = hdrw[0];
+  const uint64_t out_base = f * frame_bytes;
+  const uint32_t hdr_total = 8 + nlen + nsym + 4 * (K - 1);
+  if (err == HFZ_OK) {
+    uint64_t room = out_base <= raw_cap ? raw_cap - out_base : 0;
+    if (room > frame_bytes) room = frame_bytes;
+    if (raw_size > room) err = HFZ_E_CAPACITY;
+    if ((uint64_t)hdr_total + (uint64_t)kSlop * K > size) err = HFZ_E_CORRUPT;
+    if (nsym == 0 && raw_size != 0) err = HFZ_E_CORRUPT;
+    if (kWaves > 1) {
+      // same code section as the first frame, byte for byte: dwords 1.. up to 8 + nlen + nsym
+      const uint32_t code_end = 8 + nlen + nsym;
+      bool differs = false;
+      for (uint32_t i = 1 + lane; 4 * i < code_end; i += 64) {
+        uint32_t m = 0xffffffffu;
+        if (4 * i + 4 > code_end) m >>= 8 * (4 * i + 4 - code_end);
+        differs |= ((hdrw[i] ^ lead[i]) & m) != 0;
+      }
+      if (__any(differs) && err == HFZ_OK) err = HFZ_E_CODE_MISMATCH;
     }
-    if (lane) {
-      const uint32_t p = eo + 4 * (lane - 1);
-      begin = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
-    }
-    bad = end > area_size || begin > end || end - begin < (uint32_t)kSlop;
   }
-  if (__any(bad)) {
-    if (lane == 0 && status) status[f] = HFZ_E_CORRUPT;
+
+  // stream boundaries (codec/huffman.cpp:897-901); lanes >= K get an empty stream
+  const uint32_t area_size = err == HFZ_OK ? size - hdr_total : 0;
+  uint32_t end = kSlop, begin = 0;
+  if (err == HFZ_OK) {
+    bool bad = false;
+    if (lane < K) {
+      const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
+      if (lane < K - 1) {
+        const uint32_t p = eo + 4 * lane;
+        end = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
+      } else {
+        end = area_size;
+      }
+      if (lane) {
+        const uint32_t p = eo + 4 * (lane - 1);
+        begin = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
+      }
+      bad = end > area_size || begin > end || end - begin < (uint32_t)kSlop;
+    }
+    if (__any(bad)) err = HFZ_E_CORRUPT;
+  }
+  if (kWaves == 1 && err != HFZ_OK) {
+    if (lane == 0 && status && present) status[f] = err;
     return;
   }
   STAMP(0);  // header
@@ -1163,7 +1204,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
     if (cnt[L] == 0) continue;
     const uint32_t lo = fcode[L] >> kTabShift, hi = fcode[L + 1] >> kTabShift;
 #pragma unroll 4
-    for (uint32_t e = lo + lane; e < hi; e += 64) {
+    for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
       const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
       tab[e] = L | ((uint32_t)syms[j] << 8) | (8u << 24);
       l1tab[e] = (uint8_t)L;
@@ -1171,19 +1212,19 @@ __global__ __launch_bounds__(64) void decode_kernel(
   }
   if (kTabShift) {  // sibling pairs of 12-bit codes (their count is even: the code is complete)
     const uint32_t lo = fcode[kMaxCodeLen] >> 1;
-    for (uint32_t e = lo + lane; e < (1u << kDecTabBits); e += 64) {
+    for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
       const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
       tab[e] = kDecEsc | (uint32_t)kMaxCodeLen | ((uint32_t)syms[j] << 8) |
                ((uint32_t)syms[j + 1] << 16) | (8u << 24);
       l1tab[e] = (uint8_t)kMaxCodeLen;
     }
   }
-  wave_sync();
+  HFZ_BARRIER();
   // second symbol where both codes fit in the index bits.  Byte 1 of an entry
   // and l1tab never change in this pass, so reading another lane's entry while
   // it is being rewritten is safe.
 #pragma unroll 8
-  for (uint32_t e = lane; e < (1u << kDecTabBits); e += 64) {
+  for (uint32_t e = tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
     const uint32_t L1 = l1tab[e];
     const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
     const uint32_t L2 = l1tab[rem];
@@ -1215,7 +1256,12 @@ __global__ __launch_bounds__(64) void decode_kernel(
 
   uint32_t* const irow = iring + lane;      // dword d of this lane's input ring: irow[64 * d]
   uint32_t* const orow32 = obuf_all + lane;  // dword d of its output ring: orow32[64 * d]
-  wave_sync();  // table complete; the scratch aliased on the rings is dead
+  HFZ_BARRIER();  // table complete; the scratch aliased on the rings is dead
+#undef HFZ_BARRIER
+  if (kWaves > 1 && (err != HFZ_OK || !present)) {  // past the last barrier: waves part ways
+    if (lane == 0 && status && present) status[f] = err;
+    return;
+  }
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
   uint4 pre[4];
@@ -1507,27 +1553,31 @@ int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_c
   return hipGetLastError();
 }
 
+// d_hist != nullptr: builds d_code[f] from d_hist[f]; otherwise d_code is given,
+// one record per frame or (shared_code) one for all.
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
-                        uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  if (d_hist && shared_code) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
                      (uint32_t)K, d_raw, total, frame_bytes, d_hist, d_code,
-                     (uint32_t)(d_hist != nullptr), d_stream_end, d_csize);
+                     (uint32_t)(d_hist != nullptr), shared_code ? 0u : 1u, d_stream_end, d_csize);
   return hipGetLastError();
 }
 
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                 uint64_t n_frames, const FrameCode* d_code, uint32_t* d_counts_out,
-                 uint32_t* d_hist_out, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+                 uint64_t n_frames, const FrameCode* d_code, bool shared_code,
+                 uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
+                 uint32_t* d_csize, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   if (!count_kernel_fits(K, frame_bytes)) return hipErrorInvalidValue;
   if (d_counts_out ? d_hist_out == nullptr : d_code == nullptr) return hipErrorInvalidValue;
   hipLaunchKernelGGL(count_kernel, dim3((uint32_t)n_frames), dim3(kCntThreads), 0,
                      as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, d_code,
-                     d_counts_out, d_hist_out, d_stream_end, d_csize);
+                     shared_code ? 0u : 1u, d_counts_out, d_hist_out, d_stream_end, d_csize);
   return hipGetLastError();
 }
 
@@ -1550,23 +1600,35 @@ int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t co
 }
 
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                  uint64_t n_frames, const FrameCode* d_code, const uint32_t* d_stream_end,
-                  const uint64_t* d_comp_off, const uint32_t* d_comp_size, uint8_t* d_comp,
-                  uint64_t comp_cap, void* stream) {
+                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
+                  const uint32_t* d_stream_end, const uint64_t* d_comp_off,
+                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_raw, total, frame_bytes, d_code, d_stream_end, d_comp_off,
-                     d_comp_size, d_comp, comp_cap);
+                     (uint32_t)K, d_raw, total, frame_bytes, d_code, shared_code ? 0u : 1u,
+                     d_stream_end, d_comp_off, d_comp_size, d_comp, comp_cap);
   return hipGetLastError();
 }
 
+constexpr uint32_t kSharedWaves = 3;  // frames per workgroup when they share one code
+
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
-                  const uint32_t* d_comp_size, uint64_t n_frames, uint8_t* d_raw,
+                  const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
                   uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  // 12-bit table (29 KiB of LDS, 5 frames per CU) while that holds every frame
+  if (shared_code) {
+    // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
+    // LDS, three workgroups (nine frames) per CU and no escape entries
+    const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
+    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves>), dim3((uint32_t)groups),
+                       dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
+                       comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
+                       d_status);
+    return hipGetLastError();
+  }
+  // 12-bit table (28 KiB of LDS, 5 frames per CU) while that holds every frame
   // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
   // costs less than the extra resident waves return.
   int dev = 0, cus = 0;
@@ -1575,13 +1637,13 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     cus = 256;
   const bool wide = g_decoder_table_bits ? g_decoder_table_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
-    hipLaunchKernelGGL(decode_kernel<12>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                       (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
-                       frame_bytes, d_status);
+    hipLaunchKernelGGL((decode_kernel<12, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
+                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
   else
-    hipLaunchKernelGGL(decode_kernel<11>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                       (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, d_raw, raw_cap,
-                       frame_bytes, d_status);
+    hipLaunchKernelGGL((decode_kernel<11, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
+                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
   return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@ enum {
   HFZ_E_NO_DEVICE = -4,  /* no HIP device / HIP runtime error at start-up */
   HFZ_E_HIP = -5,        /* a HIP call failed (hfz_last_hip_error has it) */
   HFZ_E_TOO_LARGE = -6,  /* frame larger than HFZ_MAX_FRAME_BYTES */
-  HFZ_E_WORKSPACE = -7   /* workspace smaller than hfz_workspace_bytes() */
+  HFZ_E_WORKSPACE = -7,  /* workspace smaller than hfz_workspace_bytes() */
+  HFZ_E_CODE_MISMATCH = -8 /* shared-code decode: the frame's code differs from its group's */
 };
 
 /* Stream counts accepted by the GPU kernels: one wavefront lane per stream.
@@ -149,6 +150,35 @@ int hfz_decompress_batch_dev(int K, const void* d_comp, size_t comp_bytes,
                              const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                              size_t n_frames, void* d_raw, size_t raw_cap, size_t frame_bytes,
                              int32_t* d_status, void* stream);
+
+/*
+ * One code for the whole batch ("shared table").  The reference derives every
+ * frame's code from the frame itself (CompressMulti<K>, codec/huffman.cpp:755-767),
+ * so this mode has no twin there; its frames are ordinary frames all the same:
+ * each carries the code in its header and DecompressMulti<K> (or
+ * hfz_decompress*) decodes it.  Typical use: hfz_histogram_dev over the batch
+ * (sum the 256 counters across GPUs on the host), hfz_build_code_table +
+ * hfz_frame_code_from_table, copy the record to the device, pass it as d_code.
+ * Every byte value that occurs in the batch must have a code (a nonzero count in
+ * the histogram the code was built from); bytes without one are coded as garbage.
+ * Other arguments as hfz_compress_batch_dev.
+ */
+int hfz_compress_batch_shared_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                                  const hfz_frame_code* d_code, void* d_comp, size_t comp_cap,
+                                  size_t comp_stride, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                                  int32_t* d_status, void* d_ws, size_t ws_bytes, void* stream);
+
+/*
+ * Decoder for batches whose frames share one code: groups of three consecutive
+ * frames build one lookup table (from the first frame of the group) instead of
+ * three.  A frame whose code section differs from its group's first frame gets
+ * HFZ_E_CODE_MISMATCH in d_status and is left undecoded; hfz_decompress_batch_dev
+ * decodes any batch.  Arguments as hfz_decompress_batch_dev.
+ */
+int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes,
+                                    const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                                    size_t n_frames, void* d_raw, size_t raw_cap,
+                                    size_t frame_bytes, int32_t* d_status, void* stream);
 
 /* 256 byte counts (u32, wraps at 2^32) of a device buffer into d_hist[256]. */
 int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream);

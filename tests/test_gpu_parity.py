@@ -352,3 +352,69 @@ def test_enwik_like_source_32_streams(torch_cuda):
         assert batch.frame_bytes_host(i) == oracle.compress(K, host[i * frame_bytes:(i + 1) * frame_bytes]), i
     ratio = batch.compressed_bytes() / total
     assert 0.63 < ratio < 0.67  # order-0 entropy of the table is 5.1 bits/byte
+
+
+# ---- one code for the whole batch ("shared table") ---------------------------
+
+@pytest.mark.parametrize("K,total,frame_bytes,source", [
+    (64, 8 << 20, 64 << 10, "biased"),     # counting kernel, 16-bit per-stream counters
+    (32, 3 << 20, 100000, "enwik"),        # ragged last frame, 32-bit counters
+    (64, 6 << 20, 5 << 20, "biased"),      # slices beyond 65535 bytes: separate sizes pass
+    (7, 1 << 20, 30000, "biased"),
+])
+def test_shared_code_batches(torch_cuda, K, total, frame_bytes, source):
+    # Frames coded with one code for the batch are ordinary frames: the oracle's
+    # DecompressMulti<K> restatement must decode every one of them to the input,
+    # and they equal what the oracle's encoder writes given that same code.
+    torch = torch_cuda
+    raw = hfz.generate(hfz.distributions.SOURCES[source](), 42, total)
+    host = raw.cpu().numpy().tobytes()
+    codec = hfz.BatchCodec(K, total, frame_bytes)
+    hist = hfz.histogram_dev(raw)
+    assert hist.tolist() == oracle.histogram(host).tolist()
+    code = codec.code_from_histogram(hist)
+    batch = codec.compress(raw, code=code)
+    torch.cuda.synchronize()
+    assert int(codec.status.abs().sum().item()) == 0
+    coding = oracle.make_coding(oracle.histogram(host))
+    step = max(1, codec.n_frames // 6)
+    for i in list(range(0, codec.n_frames, step)) + [codec.n_frames - 1]:
+        chunk = host[i * frame_bytes:(i + 1) * frame_bytes]
+        fr = batch.frame_bytes_host(i)
+        assert oracle.decompress(K, fr) == chunk, i
+        assert fr == oracle.compress_with_coding(K, coding, chunk), i
+    # both decoders take such a batch
+    for shared in (True, False):
+        out = codec.decompress(batch, shared=shared)
+        torch.cuda.synchronize()
+        assert int(codec.dstatus.abs().sum().item()) == 0, shared
+        assert torch.equal(out, raw), shared
+
+
+def test_shared_decoder_refuses_mixed_codes(torch_cuda):
+    # per-frame codes differ from frame to frame: the shared-code decoder must say
+    # so for the frames that do not match their group's first frame, and decode
+    # the first frame of every group correctly
+    torch = torch_cuda
+    K, total, frame_bytes = 16, 12 * 20000, 20000
+    parts = []
+    for i in range(12):
+        cdf = hfz.distributions.geometric_cdf() if i % 2 else hfz.distributions.enwik_like_cdf()
+        parts.append(hfz.generate(cdf, 100 + i, frame_bytes))
+    raw = torch.cat(parts)
+    codec = hfz.BatchCodec(K, total, frame_bytes)
+    batch = codec.compress(raw)
+    out = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    codec.decompress(batch, out, shared=True)
+    torch.cuda.synchronize()
+    st = codec.dstatus.cpu().tolist()
+    for i in range(12):
+        if i % 3 == 0:
+            assert st[i] == 0
+            assert torch.equal(out[i * frame_bytes:(i + 1) * frame_bytes], parts[i])
+        elif i % 3 == 1:  # the other source: certainly another code
+            assert st[i] == hfz.HFZ_E_CODE_MISMATCH, (i, st)
+        else:
+            assert st[i] in (0, hfz.HFZ_E_CODE_MISMATCH)
+            if st[i] == 0:
+                assert torch.equal(out[i * frame_bytes:(i + 1) * frame_bytes], parts[i])
