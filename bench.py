@@ -36,9 +36,23 @@ def main():
     ap.add_argument("--frame-kib", type=int, default=256, help="raw KiB per frame")
     ap.add_argument("--source", choices=("biased", "enwik"), default="biased",
                     help="biased: P(i)=0.8^i*0.2 (reference benchmark); enwik: wiki-text-like table")
+    ap.add_argument("--shared-table", action="store_true",
+                    help="one code for the whole job: device histogram (summed over ranks), "
+                         "code built on the device, all frames coded and decoded with it")
+    ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
+                    help="preset of the named configuration: 2 = K64 256 MiB biased (default), "
+                         "3 = K32 1 GiB enwik-like, 4 = K64 8 GiB/GPU in 1 MiB frames, "
+                         "5 = K64 32 GiB/GPU in 1 MiB frames with a shared table; "
+                         "explicit flags given after it win")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
+    presets = {2: {}, 3: dict(streams=32, total_mib=1024, source="enwik"),
+               4: dict(total_mib=8192, frame_kib=1024),
+               5: dict(total_mib=32768, frame_kib=1024, shared_table=True)}
+    pre, _ = ap.parse_known_args()
+    if pre.config:
+        ap.set_defaults(**presets[pre.config])
     args = ap.parse_args()
 
     import torch
@@ -67,9 +81,37 @@ def main():
     codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
 
+    L = hfz.lib()
+    hist32 = torch.zeros(256, dtype=torch.int32, device=dev)
+    code = torch.zeros(792, dtype=torch.uint8, device=dev)
+
+    def shared_code():
+        # byte counts of this rank's batch (pieces of 2 GiB: 32-bit counters), summed
+        # over ranks: the job's one exchange, 2 KiB per GPU
+        st = torch.cuda.current_stream(dev).cuda_stream
+        h = torch.zeros(256, dtype=torch.int64, device=dev)
+        for lo in range(0, total, 1 << 31):
+            part = raw[lo:lo + (1 << 31)]
+            rc = L.hfz_histogram_dev(part.data_ptr(), part.numel(), hist32.data_ptr(), st)
+            assert rc == 0, rc
+            h += hist32.to(torch.int64) & 0xffffffff
+        if world > 1:
+            dist.all_reduce(h)
+        # counts beyond 32 bits are scaled down, every occurring symbol stays nonzero
+        shift = torch.clamp(torch.floor(torch.log2(h.max().clamp(min=1).double())) - 31, min=0).long()
+        h = torch.where(h > 0, torch.clamp(h >> shift, min=1), h)
+        h32 = (h & 0xffffffff).to(torch.int32)  # bit pattern of the unsigned count
+        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, code.data_ptr(), st)
+        assert rc == 0, rc
+        return code
+
     def step():
-        batch = codec.compress(raw)
-        codec.decompress(batch, out)
+        if args.shared_table:
+            batch = codec.compress(raw, code=shared_code())
+            codec.decompress(batch, out, shared=True)
+        else:
+            batch = codec.compress(raw)
+            codec.decompress(batch, out)
         return batch
 
     def barrier():
@@ -124,7 +166,8 @@ def main():
         pc = (prof.get("bench_line") or {}).get("config", {})
         same = all(pc.get(k) == v for k, v in (("streams", K), ("raw_mib_per_gpu", args.total_mib),
                                                ("frame_kib", args.frame_kib),
-                                               ("source", args.source)))
+                                               ("source", args.source),
+                                               ("shared_table", bool(args.shared_table))))
         if same:
             traffic = prof.get(dom + "_kernel")
     except (OSError, ValueError):
@@ -142,9 +185,13 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%d-stream encode+decode, %d MiB %s synthetic per GPU, "
-                               "per-frame tables in LDS" % (
+                               "%d KiB frames, %s" % (
                                    K, args.total_mib,
-                                   "biased-geometric" if args.source == "biased" else "enwik8-like"),
+                                   "biased-geometric" if args.source == "biased" else "enwik8-like",
+                                   args.frame_kib,
+                                   "one shared code (device histogram summed over ranks), tables "
+                                   "in LDS" if args.shared_table else "per-frame tables in LDS"),
+                   "shared_table": bool(args.shared_table),
                    "source": args.source,
                    "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
                    "frames_per_gpu": codec.n_frames, "compressed_over_raw": round(C / N, 4),
