@@ -554,40 +554,46 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
 // Consecutive lanes count different streams, so the 64 lanes of an LDS atomic
 // always fall on 32 different banks whatever the data looks like.
 constexpr uint32_t kCntThreads = 256;
-constexpr uint32_t kCntBlk = 64;  // bytes per lane per load group
+constexpr uint32_t kCntBlk = 128;  // bytes per lane per load group (the next group is in flight)
 
 __device__ __forceinline__ void count_range(const uint8_t* __restrict__ ibase, uint32_t lo,
                                             uint32_t hi, uint32_t* col, uint32_t inc) {
   if (hi <= lo) return;
+  constexpr uint32_t kQ = kCntBlk / 16;  // 16-byte loads per block
   const uint32_t first_blk = lo & ~(kCntBlk - 1);
   const uint32_t nblk = (hi + kCntBlk - 1) / kCntBlk - lo / kCntBlk;
-  uint4 cur[4], nxt[4];
+  uint4 cur[kQ], nxt[kQ];
 #pragma unroll
-  for (uint32_t q = 0; q < 4; ++q) nxt[q] = *(const uint4*)(ibase + first_blk + 16 * q);
+  for (uint32_t q = 0; q < kQ; ++q) nxt[q] = *(const uint4*)(ibase + first_blk + 16 * q);
   for (uint32_t t = 0; t < nblk; ++t) {
     const uint32_t b = first_blk + kCntBlk * t;
 #pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) cur[q] = nxt[q];
+    for (uint32_t q = 0; q < kQ; ++q) cur[q] = nxt[q];
     if (t + 1 < nblk) {
 #pragma unroll
-      for (uint32_t q = 0; q < 4; ++q) nxt[q] = *(const uint4*)(ibase + b + kCntBlk + 16 * q);
+      for (uint32_t q = 0; q < kQ; ++q) nxt[q] = *(const uint4*)(ibase + b + kCntBlk + 16 * q);
     }
-    const uint32_t w[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y,
-                            cur[1].z, cur[1].w, cur[2].x, cur[2].y, cur[2].z, cur[2].w,
-                            cur[3].x, cur[3].y, cur[3].z, cur[3].w};
     if (b >= lo && b + kCntBlk <= hi) {
 #pragma unroll
-      for (uint32_t d = 0; d < 16; ++d) {
+      for (uint32_t q = 0; q < kQ; ++q) {
+        const uint32_t w[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+        for (uint32_t d = 0; d < 4; ++d) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+        }
       }
     } else {
 #pragma unroll
-      for (uint32_t d = 0; d < 16; ++d) {
+      for (uint32_t q = 0; q < kQ; ++q) {
+        const uint32_t w[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-          const uint32_t p = b + 4 * d + j;
-          if (p >= lo && p < hi) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+        for (uint32_t d = 0; d < 4; ++d) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t p = b + 16 * q + 4 * d + j;
+            if (p >= lo && p < hi) atomicAdd(&col[((w[d] >> (8 * j)) & 0xff) * 32], inc);
+          }
         }
       }
     }
@@ -812,10 +818,15 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t* __restric
 // holds (code << 20) | len per symbol, so two codes are merged with 32-bit
 // operations before one 64-bit shift places them in the accumulator.
 constexpr uint32_t kEncBlk = 32;
-constexpr uint32_t kEncRing = 4 * kEncBlk;        // output ring bytes per stream
-constexpr uint32_t kEncOutDw = kEncRing / 4 + 1;  // output row stride (dwords)
-constexpr uint32_t kEncGroup = 4;                 // input blocks loaded at once per lane
+constexpr uint32_t kEncRingDw = 32;  // output ring per lane: 128 bytes
+constexpr uint32_t kEncGroup = 4;    // input blocks loaded at once per lane
 
+// The output ring is stored transposed and backwards: the dword at output
+// offset p (a multiple of 4) of lane l lives at ring row ~(p >> 2) & 31, LDS
+// dword [row * 64 + l].  Lane l is always on bank l % 32 (no conflicts, no
+// padding), the ring address of the dword being filled only ever grows (by one
+// row per finished dword), and an aligned 32-byte output block is one aligned
+// group of eight rows in reverse order.
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     const FrameCode* __restrict__ code, uint32_t code_step,
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
   __shared__ uint32_t enc[256];
-  __shared__ uint32_t oring[64 * kEncOutDw];
+  __shared__ uint32_t oring[64 * kEncRingDw];
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   STAMP_DECL();
@@ -862,52 +873,61 @@ __global__ __launch_bounds__(64) void encode_kernel(
   const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
   const uint32_t in_hi = in_lo + s.size;
 
-  uint32_t* const orow = oring + lane * kEncOutDw;
-  // bit writer: acc holds nb (< 32 between pairs) pending bits MSB first; wp is
-  // the output offset just above the next dword to emit (4-byte aligned).  If
-  // the stream does not end on a dword boundary the bytes above its end count
-  // as already written.
+  uint8_t* const ocol = (uint8_t*)(oring + lane);  // row r of this lane: ocol + 256 * r
+  // bit writer: acc holds nb (< 32 between pairs) pending bits MSB first.  The
+  // dword being filled sits at output offset wp - 4; ua is 256 times its ring
+  // row, not wrapped (wp = wp0 - (ua - ua0) / 64).  If the stream does not end
+  // on a dword boundary the bytes above its end count as already written.
   uint64_t acc = 0;
   uint32_t nb = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
-  uint32_t wp = (r_hi + 3) & ~3u;
+  const uint32_t wp0 = (r_hi + 3) & ~3u;
+  const uint32_t ua0 = ((~((wp0 - 4) >> 2)) & (kEncRingDw - 1)) << 8;
+  uint32_t ua = ua0;
   uint32_t nf = (r_hi - 1) & ~(kEncBlk - 1);  // next block to store (descending)
   const uint32_t nf_last = r_lo & ~(kEncBlk - 1);
   bool nf_live = true;
+  constexpr uint32_t kRowMask = (kEncRingDw - 1) << 8;
 
-  // Merges two table entries and appends them.  The dword at wp-4 is written
-  // every time (it is simply rewritten until it is complete); wp, acc and nb
-  // advance only when 32 bits have been collected.
+  // Merges two table entries and appends them.  The current dword is written
+  // every time (it is simply rewritten until it is complete); ua, acc and nb
+  // advance only when 32 bits have been collected.  Bits 4..19 of an entry are
+  // zero, so the low bits of e0 + e1 + nb are the new bit count.
 #define HFZ_PAIR(b0, b1)                                                      \
   do {                                                                        \
     const uint32_t e0_ = enc[(b0)], e1_ = enc[(b1)];                          \
     const uint32_t pair_ = (e0_ & 0xfff00000u) | ((e1_ & 0xfff00000u) >> (e0_ & 31)); \
     acc |= ((uint64_t)pair_ << 32) >> nb;                                     \
-    nb += (e0_ + e1_) & 31;                                                   \
-    orow[((wp - 4) & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);           \
-    wp -= (nb >> 5) << 2;                                                     \
-    acc <<= (nb & 32);                                                        \
-    nb &= 31;                                                                 \
+    *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);             \
+    const uint32_t nbs_ = e0_ + e1_ + nb;                                     \
+    const uint32_t full_ = nbs_ & 32;                                         \
+    ua += full_ << 3;                                                         \
+    acc <<= full_;                                                            \
+    nb = nbs_ & 31;                                                           \
   } while (0)
 #define HFZ_ONE(b0)                                                           \
   do {                                                                        \
     const uint32_t e0_ = enc[(b0)];                                           \
     acc |= ((uint64_t)(e0_ & 0xfff00000u) << 32) >> nb;                       \
-    nb += e0_ & 31;                                                           \
-    orow[((wp - 4) & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);           \
-    wp -= (nb >> 5) << 2;                                                     \
-    acc <<= (nb & 32);                                                        \
-    nb &= 31;                                                                 \
+    *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);             \
+    const uint32_t nbs_ = e0_ + nb;                                           \
+    const uint32_t full_ = nbs_ & 32;                                         \
+    ua += full_ << 3;                                                         \
+    acc <<= full_;                                                            \
+    nb = nbs_ & 31;                                                           \
   } while (0)
   // stores the ring block holding output offsets [blk, blk+32); only bytes of
   // this stream's region [r_lo, r_hi) are written
 #define HFZ_STORE_BLOCK(blk)                                                  \
   do {                                                                        \
-    const uint32_t* s_ = orow + (((blk) & (kEncRing - 1)) >> 2);              \
+    const uint8_t* g_ = ocol + (((~((blk) >> 2)) & (kEncRingDw - 8)) << 8);   \
+    uint32_t sb_[8];                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                          \
+      sb_[q_] = *(const uint32_t*)(g_ + 256 * (7 - q_));                      \
     if ((blk) >= r_lo && (blk) + kEncBlk <= r_hi) {                           \
-      *(uint4*)(obase + (blk)) = make_uint4(s_[0], s_[1], s_[2], s_[3]);      \
-      *(uint4*)(obase + (blk) + 16) = make_uint4(s_[4], s_[5], s_[6], s_[7]); \
+      *(uint4*)(obase + (blk)) = make_uint4(sb_[0], sb_[1], sb_[2], sb_[3]);  \
+      *(uint4*)(obase + (blk) + 16) = make_uint4(sb_[4], sb_[5], sb_[6], sb_[7]); \
     } else {                                                                  \
-      store_block_clipped(obase, (blk), s_, r_lo, r_hi);                      \
+      store_block_clipped(obase, (blk), sb_, r_lo, r_hi);                     \
     }                                                                         \
   } while (0)
 
@@ -960,6 +980,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
         }
       }
       // store the blocks that are complete (everything at or above wp is final)
+      const uint32_t wp = wp0 - ((ua - ua0) >> 6);
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         if (nf_live && wp <= nf) {
@@ -978,17 +999,14 @@ __global__ __launch_bounds__(64) void encode_kernel(
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
     if (nb >= 32) {
-      wp -= 4;
-      orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
+      *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);
+      ua += 256;
       acc <<= 32;
       nb -= 32;
     }
     if (z < 2) nb += 32;
   }
-  if (nb > 0) {
-    wp -= 4;
-    orow[(wp & (kEncRing - 1)) >> 2] = (uint32_t)(acc >> 32);
-  }
+  if (nb > 0) *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);
   while (nf_live) {
     HFZ_STORE_BLOCK(nf);
     if (nf == nf_last) nf_live = false;
