@@ -1346,6 +1346,11 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   uint64_t obuf = 0;
   uint32_t sh = 8 * (out_lo & 3);  // bytes below the slice start in the first dword
   uint32_t wp = out_lo & ~3u;
+  // wa = 256 * (ring row of the dword at wp), running on without wrapping: one
+  // row per finished dword.  wp itself is brought up to date once per round.
+  uint8_t* const ocol = (uint8_t*)orow32;
+  constexpr uint32_t kOutRowMask = (kDecOutDw - 1) << 8;
+  uint32_t wa = ((wp >> 2) & (kDecOutDw - 1)) << 8;
   uint32_t nfb = out_lo & ~(kDecBlk - 1);
   uint32_t left = s.size;  // symbols still to produce
   bool stream_bad = false;
@@ -1366,6 +1371,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
     uint32_t e_ = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];             \
+    /* the compiler turns this into a select (9 VALU); a forced branch      \
+       measured 3-8 % slower */                                             \
     if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e_ < 0)              \
       e_ = resolve_escape(e_, bitbuf);                                       \
     obuf |= (uint64_t)((e_ >> 8) & 0xffff) << sh;                            \
@@ -1375,10 +1382,10 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   } while (0)
 #define HFZ_DRAIN()                                                          \
   do {                                                                       \
-    orow32[64 * ((wp & (2 * kDecBlk - 1)) >> 2)] = (uint32_t)obuf;           \
+    *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;                \
     const uint32_t f_ = sh & 32;                                             \
     obuf >>= f_;                                                             \
-    wp += f_ >> 3;                                                           \
+    wa += f_ << 3;                                                           \
     sh &= 31;                                                                \
   } while (0)
   // moves the ring block holding output offsets [nfb, nfb+32) into sb[]
@@ -1416,7 +1423,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
       if (can) {
         if (left >= 2 * kDecRound) {
           // fast round: every lookup may emit two symbols without bounds checks
-          const uint32_t before = 8 * wp + sh;
+          const uint32_t wa_b = wa, sh_b = sh;
 #pragma unroll
           for (uint32_t j = 0; j < kDecRound / 4; ++j) {
             HFZ_LOOKUP();
@@ -1427,10 +1434,13 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
             HFZ_DRAIN();
             HFZ_REFILL();
           }
-          left -= (8 * wp + sh - before) >> 3;
+          const uint32_t adv = wa - wa_b;  // 256 per dword = 64 per byte
+          left -= ((adv >> 3) + sh - sh_b) >> 3;
+          wp += adv >> 6;
         } else {
           // last symbols of the slice; the final one may be the first half of
           // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
+          const uint32_t wa_b = wa;
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
             uint32_t e = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
             if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e < 0) e = resolve_escape(e, bitbuf);
@@ -1449,6 +1459,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
             if ((j & 3) == 3) HFZ_REFILL();
           }
           if (used >= 8) HFZ_REFILL();
+          wp += (wa - wa_b) >> 6;
         }
         // last round's block goes to memory, the one this round filled is read
         if (sb_full) HFZ_STORE_BLOCK();
@@ -1465,7 +1476,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   }
   if (sb_full) HFZ_STORE_BLOCK();
   // the last partial dword, then what is left in the ring: up to two blocks
-  orow32[64 * ((wp & (2 * kDecBlk - 1)) >> 2)] = (uint32_t)obuf;
+  *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (nfb < out_hi) {
