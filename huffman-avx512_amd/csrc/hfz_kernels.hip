@@ -29,7 +29,7 @@ __device__ __forceinline__ Slice slice_of(uint32_t n, uint32_t K, uint32_t k) {
 // Diagnostic build only (-DHFZ_STAMP): per-phase cycle sums of the decode
 // kernel, read back with hfz_debug_stamps().  Never compiled into libhfz.so.
 #ifdef HFZ_STAMP
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[32];
 #define STAMP_DECL() unsigned long long st_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[8] = {}
 #define STAMP(i)                                                    \
   do {                                                              \
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ r
 // libstdc++'s std::sort (:353-354), so that algorithm is followed step by
 // step: the introsort partition loop (median of three to the front, unguarded
 // Hoare partition, segments of at most 16 left alone, heapsort once the depth
-// budget 2*floor(log2 n) is spent) runs serially on lane 0; the insertion sort
+// budget 2*floor(log2 n) is spent) is reproduced swap for swap, each partition
+// evaluated by the whole wave (see introsort_loop); the insertion sort
 // that finishes std::sort is stable, so its result is the stable order of the
 // partitioned array and all lanes compute it as ranks.  The two-queue Huffman
 // merge (:364-416, a leaf wins a tie, :375) is serial as well; depths come from
@@ -222,51 +223,136 @@ __device__ void heap_sort_range(const SortArrays& a, int first, int last) {
   }
 }
 
-// std::__introsort_loop with its recursion on an explicit stack
-__device__ void introsort_loop(const SortArrays& a, int n, int* stk) {
+// std::__introsort_loop with its recursion on an explicit stack, run by the
+// whole wave: first, last, depth and sp are wave-uniform.  The unguarded Hoare
+// partition (std::__unguarded_partition) is evaluated in parallel.  Serially it
+// alternates "i up to the next element not before the pivot" / "j down to the
+// next element not after the pivot" and swaps while i < j; elements it has
+// swapped are never looked at again before the loop ends, so the t-th swap pairs
+// the t-th such element from the left (llist[t]) with the t-th from the right
+// (rlist[t]) of the ORIGINAL segment, for exactly the t with llist[t] < rlist[t]
+// (a prefix: one list ascends, the other descends).  When the loop ends after T
+// swaps, i stands on the next left candidate or on the last swapped right
+// position, whichever comes first.
+__device__ void introsort_loop(const SortArrays& a, int n, int* stk, uint32_t* llist,
+                               uint32_t* rlist, uint32_t lane) {
   int depth = 0;
   for (int v = n; v > 1; v >>= 1) ++depth;
   depth *= 2;
   int sp = 0, first = 0, last = n;
+  const uint64_t below_me = (1ull << lane) - 1;
   for (;;) {
     while (last - first > 16) {
       if (depth == 0) {
-        heap_sort_range(a, first, last);
+        if (lane == 0) heap_sort_range(a, first, last);
+        wave_sync();
         break;
       }
       --depth;
       // __move_median_to_first(first, first+1, mid, last-1)
       const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+      const uint32_t kx = a.key[x], ky = a.key[y], kz = a.key[z];
       int m;
-      if (sort_less(a, x, y)) {
-        m = sort_less(a, y, z) ? y : (sort_less(a, x, z) ? z : x);
+      if (kx > ky) {
+        m = ky > kz ? y : (kx > kz ? z : x);
       } else {
-        m = sort_less(a, x, z) ? x : (sort_less(a, y, z) ? z : y);
+        m = kx > kz ? x : (ky > kz ? z : y);
       }
-      sort_swap(a, first, m);
+      m = __builtin_amdgcn_readfirstlane(m);
+      wave_sync();
+      if (lane == 0) sort_swap(a, first, m);
+      wave_sync();
+      const uint32_t pk = __builtin_amdgcn_readfirstlane(a.key[first]);
       // __unguarded_partition(first+1, last, first)
-      const uint32_t pk = a.key[first];
-      int i = first + 1, j = last;
-      for (;;) {
-        while (a.key[i] > pk) ++i;
-        --j;
-        while (pk > a.key[j]) --j;
-        if (!(i < j)) break;
-        sort_swap(a, i, j);
-        ++i;
+      const int base = first + 1;
+      const int len = last - base;  // 16..255
+      uint64_t lb[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (64 * q < len) {
+          const int p = base + 64 * q + (int)lane;
+          const bool in = p < last;
+          const uint32_t k = in ? a.key[p] : 0;
+          lb[q] = __ballot(in && k <= pk);  // not before the pivot: stops i
+          rb[q] = __ballot(in && k >= pk);  // not after the pivot: stops j
+        }
       }
-      // recurse on [i, last) with the reduced depth, continue with [first, i)
-      stk[3 * sp] = i;
-      stk[3 * sp + 1] = last;
-      stk[3 * sp + 2] = depth;
+      uint32_t lpre = 0;
+      uint32_t rabove = __popcll(rb[0]) + __popcll(rb[1]) + __popcll(rb[2]) + __popcll(rb[3]);
+      const uint32_t n_r = rabove;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (64 * q < len) {
+          const uint32_t p = (uint32_t)(base + 64 * q) + lane;
+          rabove -= __popcll(rb[q]);  // candidates in the chunks above this one
+          if ((lb[q] >> lane) & 1) llist[lpre + __popcll(lb[q] & below_me)] = p;
+          if ((rb[q] >> lane) & 1) rlist[rabove + __popcll(rb[q] & ~below_me) - 1] = p;
+          lpre += __popcll(lb[q]);
+        }
+      }
+      const uint32_t n_l = lpre;
+      wave_sync();
+      const uint32_t n_min = n_l < n_r ? n_l : n_r;
+      uint32_t T = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)(64 * q) < n_min) {
+          const uint32_t t = 64 * q + lane;
+          const bool c = t < n_min && llist[t] < rlist[t];
+          T += __popcll(__ballot(c));
+        }
+      }
+      uint32_t cut = 0xffffffffu;
+      if (T < n_l) cut = llist[T];
+      if (T > 0) {
+        const uint32_t r = rlist[T - 1];
+        cut = r < cut ? r : cut;
+      }
+      cut = __builtin_amdgcn_readfirstlane(cut);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)(64 * q) < T) {
+          const uint32_t t = 64 * q + lane;
+          if (t < T) sort_swap(a, (int)llist[t], (int)rlist[t]);
+        }
+      }
+      wave_sync();
+      // recurse on [cut, last) with the reduced depth, continue with [first, cut)
+      if (lane == 0) {
+        stk[3 * sp] = (int)cut;
+        stk[3 * sp + 1] = last;
+        stk[3 * sp + 2] = depth;
+      }
       ++sp;
-      last = i;
+      last = (int)cut;
     }
     if (sp == 0) return;
     --sp;
-    first = stk[3 * sp];
-    last = stk[3 * sp + 1];
-    depth = stk[3 * sp + 2];
+    wave_sync();
+    first = __builtin_amdgcn_readfirstlane(stk[3 * sp]);
+    last = __builtin_amdgcn_readfirstlane(stk[3 * sp + 1]);
+    depth = __builtin_amdgcn_readfirstlane(stk[3 * sp + 2]);
+  }
+}
+
+// Element i of a 256-entry array kept in four registers across the wave; i is
+// wave-uniform.
+__device__ __forceinline__ uint32_t lane_get(const uint32_t (&a)[4], int i) {
+  const int l = i & 63;
+  switch (i >> 6) {
+    case 0: return __builtin_amdgcn_readlane(a[0], l);
+    case 1: return __builtin_amdgcn_readlane(a[1], l);
+    case 2: return __builtin_amdgcn_readlane(a[2], l);
+    default: return __builtin_amdgcn_readlane(a[3], l);
+  }
+}
+__device__ __forceinline__ void lane_set(uint32_t (&a)[4], int i, uint32_t v, uint32_t lane) {
+  const bool mine = lane == (uint32_t)(i & 63);
+  switch (i >> 6) {
+    case 0: a[0] = mine ? v : a[0]; break;
+    case 1: a[1] = mine ? v : a[1]; break;
+    case 2: a[2] = mine ? v : a[2]; break;
+    default: a[3] = mine ? v : a[3]; break;
   }
 }
 
@@ -276,12 +362,12 @@ __device__ void introsort_loop(const SortArrays& a, int n, int* stk) {
 // a larger workgroup calls it from a single wave and synchronises afterwards.
 __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, FrameCode* __restrict__ out_p,
                                                       uint32_t lane) {
-  __shared__ uint32_t key[256], key2[256], tcount[256], lcount[256];
+  __shared__ uint32_t key[256], key2[256], tcount[256], lcount[256];  // tcount: sort scratch
   __shared__ uint8_t sym[256], sym2[256];
   __shared__ uint16_t parent[2][256], depthv[2][256], lparent[256], encs[256];
   __shared__ uint32_t hdrw[70];
   __shared__ int stk[3 * 40];
-  __shared__ int tree_size_s;
+  STAMP_DECL();
 
   // symbols with a nonzero count, ascending (:342-347)
   const uint4 h4 = *(const uint4*)(hist + 4 * lane);
@@ -290,7 +376,8 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
 #pragma unroll
   for (int j = 0; j < 4; ++j) nz += hv[j] != 0;
   const uint32_t incl = wave_inclusive_scan(nz, lane);
-  const int n = (int)__shfl(incl, 63, 64);
+  // n is the same in every lane; saying so keeps everything derived from it in scalar registers
+  const int n = __builtin_amdgcn_readfirstlane((int)__shfl(incl, 63, 64));
   uint32_t pos = incl - nz;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -304,9 +391,11 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   }
   wave_sync();
 
+  STAMP(0);  // compaction
   const SortArrays arr = {sym, key};
-  if (lane == 0 && n > 16) introsort_loop(arr, n, stk);
+  if (n > 16) introsort_loop(arr, n, stk, tcount, key2, lane);  // both lists are free until later
   wave_sync();
+  STAMP(1);  // partition loop
   // stable order by descending count = what the final insertion sort leaves
   for (int i = (int)lane; i < n; i += 64) {
     const uint32_t k = key[i];
@@ -320,29 +409,45 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   }
   wave_sync();
 
-  // two-queue Huffman merge; records each leaf's and node's parent
-  if (lane == 0) {
-    int ns = n - 1, nt = 0, ts = 0;
+  STAMP(2);  // rank sort
+  // Two-queue Huffman merge (:364-416); records each leaf's and node's parent.
+  // Inherently serial, so it runs as wave-uniform scalar code with both queues in
+  // registers (element i = lane i & 63 of register i >> 6, read and written
+  // with v_readlane / v_writelane): a step costs a few scalar instructions
+  // instead of two dependent LDS round trips.
+  uint32_t kq[4], tq[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kq[r] = key2[64 * r + lane];
+  int ts = 0;
+  {
+    int ns = n - 1, nt = 0;
+    uint32_t lk = ns >= 0 ? lane_get(kq, ns) : 0;  // head of the leaf queue
+    uint32_t nk = 0;                               // head of the node queue (valid if nt < ts)
     while ((ts - nt) + (ns + 1) > 1) {
       uint32_t sum = 0;
+#pragma unroll
       for (int t = 0; t < 2; ++t) {
-        bool leaf = false;
-        if (ns >= 0) leaf = nt == ts || key2[ns] <= tcount[nt];
+        const bool leaf = ns >= 0 && (nt == ts || lk <= nk);  // a leaf wins a tie (:375)
         if (leaf) {
-          sum += key2[ns];
-          lparent[ns--] = (uint16_t)ts;
+          sum += lk;
+          if (lane == 0) lparent[ns] = (uint16_t)ts;
+          --ns;
+          if (ns >= 0) lk = lane_get(kq, ns);
         } else {
-          sum += tcount[nt];
-          parent[0][nt++] = (uint16_t)ts;
+          sum += nk;
+          if (lane == 0) parent[0][nt] = (uint16_t)ts;
+          ++nt;
+          if (nt < ts) nk = lane_get(tq, nt);
         }
       }
-      tcount[ts++] = sum;
+      lane_set(tq, ts, sum, lane);
+      if (nt == ts) nk = sum;  // the queue was empty: the new node is its head
+      ++ts;
     }
-    tree_size_s = ts;
-    if (ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
+    if (lane == 0 && ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
   }
   wave_sync();
-  const int ts = tree_size_s;
+  STAMP(3);  // merge
   if (ts == 0) {
     if (lane == 0 && n == 1) lcount[0] = 1;  // a single symbol: zero-length code
   } else {
@@ -364,33 +469,42 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   }
   wave_sync();
 
-  // LimitCodeLengths (:297-327)
-  if (lane == 0 && n > 0) {
+  STAMP(4);  // depths
+  // LimitCodeLengths (:297-327) on wave-uniform registers: lengths beyond 12
+  // fold into 12, then MiniZ's fix-up loop
+  uint32_t lc[kMaxCodeLen + 1];
+  {
     uint32_t over = 0;
-    for (int i = kMaxCodeLen + 1; i < 256; ++i) over += lcount[i];
-    lcount[kMaxCodeLen] += over;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * lane + j > (uint32_t)kMaxCodeLen) over += lcount[4 * lane + j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) over += __shfl_xor(over, d, 64);
+#pragma unroll
+    for (int L = 0; L <= kMaxCodeLen; ++L) lc[L] = __builtin_amdgcn_readfirstlane(lcount[L]);
+    lc[kMaxCodeLen] += __builtin_amdgcn_readfirstlane(over);
     uint32_t kraft = 0;
-    for (int i = 0; i <= kMaxCodeLen; ++i) kraft += lcount[i] << (kMaxCodeLen - i);
+#pragma unroll
+    for (int L = 0; L <= kMaxCodeLen; ++L) kraft += lc[L] << (kMaxCodeLen - L);
     while (kraft > (1u << kMaxCodeLen)) {
-      --lcount[kMaxCodeLen];
+      --lc[kMaxCodeLen];
+      bool done = false;
+#pragma unroll
       for (int j = kMaxCodeLen - 1; j >= 0; --j) {
-        if (lcount[j] > 0) {
-          --lcount[j];
-          lcount[j + 1] += 2;
-          break;
+        if (!done && lc[j] > 0) {
+          --lc[j];
+          lc[j + 1] += 2;
+          done = true;
         }
       }
       --kraft;
     }
   }
-  wave_sync();
-
+  STAMP(5);  // length limit
   // canonical codes in sorted order (ForallCodes, :260-284) and header bytes
-  uint32_t lc[kMaxCodeLen + 1];
   uint32_t len_mask = 0, nlen = 0;
 #pragma unroll
   for (int L = 0; L <= kMaxCodeLen; ++L) {
-    lc[L] = lcount[L];
     if (lc[L]) {
       len_mask |= 1u << L;
       ++nlen;
@@ -431,6 +545,8 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   uint32_t* hdr_out = (uint32_t*)out.hdr;
   for (uint32_t i = lane; i < 69; i += 64) hdr_out[i] = hdrw[i];
   if (lane == 0) out.hdr_len = 4 + nlen + (uint32_t)n;
+  STAMP(6);  // canonical codes, header, write-out
+  STAMP_FLUSH(16);
   return encs;
 }
 
@@ -1688,9 +1804,9 @@ int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, 
 
 #ifdef HFZ_STAMP
 extern "C" int hfz_debug_stamps(unsigned long long* out, int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
   if (e == hipSuccess && reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
   }
   return (int)e;

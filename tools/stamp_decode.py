@@ -8,7 +8,7 @@ import torch
 hfz = importlib.import_module("huffman-avx512_amd")
 hfz.LIB_PATH = os.path.join(ROOT, "tools", "libhfz_stamp.so")
 L = hfz.lib()
-from bench import geometric_cdf
+geometric_cdf = hfz.distributions.geometric_cdf
 names = ["header", "table", "priming", "staging", "rounds", "-", "-", "tail"]
 for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     total = 256 << 20
@@ -17,7 +17,7 @@ for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     batch = codec.compress(raw)
     out = torch.empty(total, dtype=torch.uint8, device="cuda")
     codec.decompress(batch, out); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     L.hfz_debug_stamps(buf, 1)
     codec.compress(raw); codec.decompress(batch, out); torch.cuda.synchronize()
     L.hfz_debug_stamps(buf, 1)
@@ -27,4 +27,7 @@ for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     et = sum(buf[8:16])
     print("  encode cycles/wave %.0f" % (et / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[8 + i] / et)
           for i, n in enumerate(["table+header", "setup", "-", "main loop", "tail"])))
+    bt = sum(buf[16:24])
+    print("  build_code ticks(100MHz)/frame %.0f" % (bt / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[16 + i] / max(bt, 1))
+          for i, n in enumerate(["compact", "partition", "rank", "merge", "depths", "limit", "emit"])))
     print("equal:", bool(torch.equal(out, raw)))
