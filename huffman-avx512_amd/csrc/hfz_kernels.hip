@@ -943,38 +943,52 @@ constexpr uint32_t kEncGroup = 4;    // input blocks loaded at once per lane
 // padding), the ring address of the dword being filled only ever grows (by one
 // row per finished dword), and an aligned 32-byte output block is one aligned
 // group of eight rows in reverse order.
+//
+// kF = frames per wave.  With K <= 32 a frame would leave half the lanes idle,
+// so lanes 0..31 take frame 2b and lanes 32..63 frame 2b+1 of workgroup b (each
+// half with its own code table); everything past the prologue is per lane anyway.
+template <uint32_t kF>
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
-    const FrameCode* __restrict__ code, uint32_t code_step,
+    uint64_t n_frames, const FrameCode* __restrict__ code, uint32_t code_step,
     const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
-  __shared__ uint32_t enc[256];
+  static_assert(kF == 1 || kF == 2, "one or two frames per wave");
+  __shared__ uint32_t enc_all[kF * 256];
   __shared__ uint32_t oring[64 * kEncRingDw];
-  const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
+  const uint32_t half = kF == 1 ? 0 : lane >> 5;
+  const uint32_t k = kF == 1 ? lane : lane & 31;  // stream index within the frame
+  constexpr uint32_t kSub = 64 / kF;              // lanes per frame
+  const uint64_t f_real = (uint64_t)blockIdx.x * kF + half;
+  const bool present = f_real < n_frames;
+  const uint64_t f = present ? f_real : 0;
+  uint32_t* const enc = enc_all + 256 * half;
   STAMP_DECL();
   const FrameCode& fc = code[f * code_step];
-  for (uint32_t i = lane; i < 256; i += 64) {
+  for (uint32_t i = k; i < 256; i += kSub) {
     const uint32_t e = fc.enc[i];
     enc[i] = ((e >> 4) << 20) | (e & 15);
   }
 
   const uint64_t off = comp_off[f];
   const uint32_t size = comp_size[f];
-  if (off > cap || size > cap - off) return;  // reported by offsets_kernel
-  uint8_t* out = comp + off;
+  const bool ok = present && !(off > cap || size > cap - off);  // else reported by offsets_kernel
+  uint8_t* out = comp + (ok ? off : 0);
   const uint32_t n = frame_len(total, frame_bytes, f);
   const uint32_t hdr_len = fc.hdr_len;
   const uint32_t hdr_total = 4 + hdr_len + 4 * (K - 1);
 
   // header: raw_size | len_mask | counts | sorted symbols | K-1 end offsets
-  if (lane < 4) out[lane] = (uint8_t)(n >> (8 * lane));
-  for (uint32_t i = lane; i < hdr_len; i += 64) out[4 + i] = fc.hdr[i];
-  if (lane < K - 1) store_u32u(out + 4 + hdr_len + 4 * lane, stream_end[f * 64 + lane]);
+  if (ok) {
+    if (k < 4) out[k] = (uint8_t)(n >> (8 * k));
+    for (uint32_t i = k; i < hdr_len; i += kSub) out[4 + i] = fc.hdr[i];
+    if (k < K - 1) store_u32u(out + 4 + hdr_len + 4 * k, stream_end[f * 64 + k]);
+  }
   wave_sync();  // enc[] complete
   STAMP(0);  // table + header
-  if (lane >= K) return;
+  if (!ok || k >= K) return;
 
   // input: offsets from ibase, the 32-byte block holding the frame's first raw
   // byte; output: offsets from obase likewise (pointer arithmetic keeps both in
@@ -982,10 +996,10 @@ __global__ __launch_bounds__(64) void encode_kernel(
   const uint8_t* const frame_in = raw + f * frame_bytes;
   const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);
   uint8_t* const obase = out - ((uintptr_t)out & 31);
-  const Slice s = slice_of(n, K, lane);
+  const Slice s = slice_of(n, K, k);
   const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
-  const uint32_t r_hi = area + stream_end[f * 64 + lane];
-  const uint32_t r_lo = area + (lane ? stream_end[f * 64 + lane - 1] : 0);
+  const uint32_t r_hi = area + stream_end[f * 64 + k];
+  const uint32_t r_lo = area + (k ? stream_end[f * 64 + k - 1] : 0);
   const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
   const uint32_t in_hi = in_lo + s.size;
 
@@ -1744,19 +1758,36 @@ int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t co
   return hipGetLastError();
 }
 
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  return cus;
+}
+
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_raw, total, frame_bytes, d_code, shared_code ? 0u : 1u,
-                     d_stream_end, d_comp_off, d_comp_size, d_comp, comp_cap);
+  // two frames per wave once the pairs still give every SIMD a wave
+  if (K <= 32 && n_frames > 4 * (uint64_t)device_cus())
+    hipLaunchKernelGGL(encode_kernel<2>, dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames, d_code,
+                       shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size, d_comp,
+                       comp_cap);
+  else
+    hipLaunchKernelGGL(encode_kernel<1>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                       (uint32_t)K, d_raw, total, frame_bytes, n_frames, d_code,
+                       shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size, d_comp,
+                       comp_cap);
   return hipGetLastError();
 }
 
 constexpr uint32_t kSharedWaves = 3;  // frames per workgroup when they share one code
+
 
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
@@ -1776,10 +1807,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // 12-bit table (28 KiB of LDS, 5 frames per CU) while that holds every frame
   // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
   // costs less than the extra resident waves return.
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    cus = 256;
+  const int cus = device_cus();
   const bool wide = g_decoder_table_bits ? g_decoder_table_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
     hipLaunchKernelGGL((decode_kernel<12, 1>), dim3((uint32_t)n_frames), dim3(64), 0,

@@ -64,6 +64,9 @@ def lib():
         L.ho_time_roundtrip.restype = ci
         L.ho_time_roundtrip.argtypes = [ci, vp, sz, sz, ci, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
+        L.ho_time_roundtrip_mt.restype = ci
+        L.ho_time_roundtrip_mt.argtypes = [ci, vp, sz, sz, ci, ci, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -169,11 +172,17 @@ def generate(cdf, seed, n, first_index=0):
     return out[:n]
 
 
-def time_roundtrip(K, raw, frame_bytes, reps=1):
+def time_roundtrip(K, raw, frame_bytes, reps=1, threads=1):
+    """Seconds spent compressing / decompressing `raw` frame by frame, `reps` times;
+    threads > 1 spreads the frames of each phase over that many POSIX threads."""
     p, n, keep = _buf(raw)
     tc, td, ct = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
-    rc = lib().ho_time_roundtrip(K, p, n, frame_bytes, reps, ctypes.byref(tc), ctypes.byref(td),
-                                 ctypes.byref(ct))
+    if threads > 1:
+        rc = lib().ho_time_roundtrip_mt(K, p, n, frame_bytes, reps, threads, ctypes.byref(tc),
+                                        ctypes.byref(td), ctypes.byref(ct))
+    else:
+        rc = lib().ho_time_roundtrip(K, p, n, frame_bytes, reps, ctypes.byref(tc),
+                                     ctypes.byref(td), ctypes.byref(ct))
     if rc != 0:
         raise RuntimeError("oracle round trip failed: %d" % rc)
     return tc.value, td.value, ct.value

@@ -8,6 +8,7 @@
 #include "huffman_oracle.h"
 
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 #include <time.h>
 
@@ -668,6 +669,75 @@ static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* One worker of ho_time_roundtrip_mt: frames tid, tid + threads, ... */
+typedef struct {
+  int K, tid, threads, phase, rc;
+  const uint8_t* raw;
+  size_t total, frame_bytes, nframes, bound;
+  uint8_t *comp, *back;
+  size_t* csz;
+} ho_worker;
+
+static void* ho_worker_run(void* arg) {
+  ho_worker* w = (ho_worker*)arg;
+  for (size_t f = (size_t)w->tid; f < w->nframes; f += (size_t)w->threads) {
+    size_t off = f * w->frame_bytes;
+    size_t len = w->total - off < w->frame_bytes ? w->total - off : w->frame_bytes;
+    if (w->phase == 0) {
+      w->csz[f] = ho_compress(w->K, w->raw + off, len, w->comp + f * w->bound, w->bound);
+    } else {
+      long got = ho_decompress(w->K, w->comp + f * w->bound, w->csz[f], w->back + off, len);
+      if (got != (long)len) w->rc = 1;
+    }
+  }
+  return NULL;
+}
+
+/* As ho_time_roundtrip, with the frames of each phase spread over `threads`
+ * POSIX threads (independent frames, the way a multi-core user of the
+ * reference would run it); times are wall-clock per phase. */
+int ho_time_roundtrip_mt(int K, const uint8_t* raw, size_t total, size_t frame_bytes, int reps,
+                         int threads, double* t_c, double* t_d, size_t* comp_total) {
+  if (frame_bytes == 0 || K < 1 || threads < 1 || threads > 256) return 2;
+  size_t nframes = (total + frame_bytes - 1) / frame_bytes;
+  size_t bound = ho_compress_bound(frame_bytes, K);
+  uint8_t* comp = (uint8_t*)malloc(bound * (nframes ? nframes : 1));
+  size_t* csz = (size_t*)calloc(nframes ? nframes : 1, sizeof(size_t));
+  uint8_t* back = (uint8_t*)malloc(total ? total : 1);
+  ho_worker* ws = (ho_worker*)calloc((size_t)threads, sizeof(ho_worker));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  if (!comp || !csz || !back || !ws || !th) {
+    free(comp); free(csz); free(back); free(ws); free(th);
+    return 3;
+  }
+  double tc = 0, td = 0;
+  int rc = 0;
+  for (int r = 0; r < reps; ++r) {
+    for (int phase = 0; phase < 2; ++phase) {
+      double t0 = now_s();
+      for (int t = 0; t < threads; ++t) {
+        ho_worker w = {K, t, threads, phase, 0, raw, total, frame_bytes, nframes, bound, comp, back, csz};
+        ws[t] = w;
+        if (pthread_create(&th[t], NULL, ho_worker_run, &ws[t]) != 0) { ho_worker_run(&ws[t]); th[t] = 0; }
+      }
+      for (int t = 0; t < threads; ++t) {
+        if (th[t]) pthread_join(th[t], NULL);
+        if (ws[t].rc) rc = 1;
+      }
+      double t1 = now_s();
+      if (phase == 0) tc += t1 - t0; else td += t1 - t0;
+    }
+  }
+  size_t ctot = 0;
+  for (size_t f = 0; f < nframes; ++f) ctot += csz[f];
+  if (memcmp(back, raw, total) != 0) rc = 1;
+  *t_c = tc;
+  *t_d = td;
+  *comp_total = ctot;
+  free(comp); free(csz); free(back); free(ws); free(th);
+  return rc;
 }
 
 int ho_time_roundtrip(int K, const uint8_t* raw, size_t total, size_t frame_bytes,

@@ -96,6 +96,8 @@ void ho_generate(const uint32_t cdf[256], uint64_t seed, uint64_t first_index,
  * ho_decompress over `frames` frames of `frame_bytes` each, `reps` times,
  * single thread; returns seconds for compress in *t_c and decompress in *t_d.
  * Returns 0 on success, nonzero if a round trip mismatched. */
+int ho_time_roundtrip_mt(int K, const uint8_t* raw, size_t total, size_t frame_bytes, int reps,
+                         int threads, double* t_c, double* t_d, size_t* comp_total);
 int ho_time_roundtrip(int K, const uint8_t* raw, size_t total, size_t frame_bytes,
                       int reps, double* t_c, double* t_d, size_t* comp_total);
 
