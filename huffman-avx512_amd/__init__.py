@@ -37,7 +37,7 @@ EXPORTS = (
     "hfz_compress_batch_dev", "hfz_decompress_batch_dev", "hfz_histogram_dev",
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
     "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
-    "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev",
+    "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
 )
 
 
@@ -129,6 +129,8 @@ def lib():
         L.hfz_build_codes_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_timing_enable.restype = ci
         L.hfz_timing_enable.argtypes = [ci]
+        L.hfz_set_frames_per_wave.restype = ci
+        L.hfz_set_frames_per_wave.argtypes = [ci]
         L.hfz_set_decoder_table_bits.restype = ci
         L.hfz_set_decoder_table_bits.argtypes = [ci]
         L.hfz_timing_read.restype = ci
@@ -372,6 +374,11 @@ def shard_frames(n_frames, rank, world):
 def set_decoder_table_bits(bits=0):
     """0 = automatic, 11 or 12 = force that build of the decoder's lookup table."""
     _check(lib().hfz_set_decoder_table_bits(int(bits)), "hfz_set_decoder_table_bits")
+
+
+def set_frames_per_wave(n=0):
+    """0 = automatic, 1 = one frame per wave, 2 = two (K <= 32)."""
+    _check(lib().hfz_set_frames_per_wave(int(n)), "hfz_set_frames_per_wave")
 
 
 def timing_enable(on=True):

@@ -378,6 +378,12 @@ int hfz_set_decoder_table_bits(int bits) {
   return HFZ_OK;
 }
 
+int hfz_set_frames_per_wave(int n) {
+  if (n < 0 || n > 2) return HFZ_E_ARG;
+  g_frames_per_wave = n;
+  return HFZ_OK;
+}
+
 int hfz_timing_enable(int on) {
   g_timing.on = on != 0;
   g_timing.enc_calls = g_timing.dec_calls = 0;

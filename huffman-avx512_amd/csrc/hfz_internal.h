@@ -54,6 +54,8 @@ inline WorkspaceLayout workspace_layout(size_t n) {
 
 // 0 = choose by frame count, 11 / 12 = forced (hfz_set_decoder_table_bits).
 extern int g_decoder_table_bits;
+// 0 = choose by frame count, 1 / 2 = forced (hfz_set_frames_per_wave).
+extern int g_frames_per_wave;
 
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);

@@ -1198,29 +1198,34 @@ __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) 
   return (uint32_t)kMaxCodeLen | (sym << 8) | (8u << 24);
 }
 
-// kWaves = 1: one frame per workgroup, every frame builds its own table.
+// kWaves = 1: one frame per wave and workgroup, every frame builds its own table.
 // kWaves > 1 (shared-code batches): kWaves frames per workgroup, one wave each;
 // the table is built once, by all waves, from the header of the workgroup's
 // first frame, and a frame whose code section differs from that one is refused
 // (HFZ_E_CODE_MISMATCH) instead of being decoded with the wrong table.
-template <uint32_t kDecTabBits, uint32_t kWaves>
+// kF = 2 (K <= 32, kWaves = 1): lanes 0..31 decode frame 2b, lanes 32..63 frame
+// 2b+1 of workgroup b.  The prologue (header, table) runs once per frame with
+// all 64 lanes helping; the lanes of the frame's half keep its parameters.
+template <uint32_t kDecTabBits, uint32_t kWaves, uint32_t kF>
 __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint64_t n_frames, uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
-  __shared__ uint32_t tab[1u << kDecTabBits];
+  static_assert(kF == 1 || (kF == 2 && kWaves == 1), "two frames per wave only without table sharing");
+  __shared__ uint32_t tab[kF << kDecTabBits];
   __shared__ uint32_t ringmem[kWaves * 64 * (kDecInDw + kDecOutDw)];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
   const uint32_t wave = kWaves == 1 ? 0 : tid >> 6;
+  const uint32_t half = kF == 1 ? 0 : lane >> 5;
+  const uint32_t k = kF == 1 ? lane : lane & 31;  // stream index within the frame
   uint32_t* const iring = ringmem + wave * 64 * (kDecInDw + kDecOutDw);
   uint32_t* const obuf_all = iring + 64 * kDecInDw;
-  // scratch that is only live while the table is built (on the first wave's input rings)
+  // scratch that is only live while a table is built (on the first wave's input rings)
   uint8_t* const l1tab = (uint8_t*)ringmem;
   static_assert(sizeof(uint32_t) * 64 * kDecInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
   static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
-  const uint64_t f = (uint64_t)blockIdx.x * kWaves + wave;
   STAMP_DECL();
 #define HFZ_BARRIER()                 \
   do {                                \
@@ -1228,158 +1233,193 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     else __syncthreads();             \
   } while (0)
 
-  // Every wave stages its frame's header: one round trip brings all of it (at
-  // most 8 + 13 + 256 + 4*63 bytes) into LDS; everything below parses it there.
-  const bool present = f < n_frames;
-  uint64_t off = 0;
-  uint32_t size = 0;
-  if (present) {
-    off = comp_off[f];
-    size = comp_size[f];
-  }
+  // what a lane keeps of its frame
+  uint64_t f = 0;
+  bool present = false;
   int err = HFZ_OK;
-  if (off > comp_bytes || size > comp_bytes - off || size < 8) {
-    err = HFZ_E_CORRUPT;
-    size = 0;
-  }
-  const uint8_t* in = comp + (err == HFZ_OK ? off : 0);
-  uint32_t* const hdrw = obuf_all;  // 192 dwords, dead once the streams start
+  const uint8_t* in = comp;
+  uint32_t raw_size = 0, hdr_total = 0, end = kSlop;
+
 #pragma unroll
-  for (uint32_t j = 0; j < 3; ++j) {
-    const uint32_t idx = lane + 64 * j;
-    uint32_t v = 0;
-    if (4 * idx + 4 <= size) {
-      v = load_u32u(in + 4 * idx);
-    } else {
-      for (uint32_t b = 0; b < 4; ++b)
-        if (4 * idx + b < size) v |= (uint32_t)in[4 * idx + b] << (8 * b);
+  for (uint32_t pass = 0; pass < kF; ++pass) {
+    const bool mine = kF == 1 || half == pass;
+    const uint64_t pf = ((uint64_t)blockIdx.x * kWaves + wave) * kF + pass;
+    // The frame's header: one round trip brings all of it (at most 8 + 13 + 256
+    // + 4*63 bytes) into LDS; everything below parses it there.
+    const bool p_present = pf < n_frames;
+    uint64_t off = 0;
+    uint32_t size = 0;
+    if (p_present) {
+      off = comp_off[pf];
+      size = comp_size[pf];
     }
-    hdrw[idx] = v;
-  }
-  HFZ_BARRIER();
-
-  // The code section (len_mask, per-length counts, canonical symbol order) is
-  // read from the workgroup's first frame, which is this frame when kWaves = 1.
-  // ParseCompressedHeader (codec/huffman.cpp:714-736) + canonical code starts
-  // (ForallCodes, codec/huffman.cpp:260-284).
-  const uint32_t* const lead = ringmem + 64 * kDecInDw;
-  const uint8_t* const hb = (const uint8_t*)lead;
-  const uint32_t len_mask = lead[1];
-  const uint32_t nlen = __popc(len_mask);
-  int lead_err = HFZ_OK;
-  if ((len_mask >> (kMaxCodeLen + 1)) != 0) lead_err = HFZ_E_CORRUPT;
-  uint32_t cnt[kMaxCodeLen + 1], fcode[kMaxCodeLen + 2], soff[kMaxCodeLen + 1];
-  uint32_t cur = 0, nsym = 0, hp = 8;
+    int p_err = HFZ_OK;
+    if (off > comp_bytes || size > comp_bytes - off || size < 8) {
+      p_err = HFZ_E_CORRUPT;
+      size = 0;
+    }
+    const uint8_t* p_in = comp + (p_err == HFZ_OK ? off : 0);
+    uint32_t* const hdrw = obuf_all;  // 192 dwords, dead once the streams start
 #pragma unroll
-  for (int L = 0; L <= kMaxCodeLen; ++L) {
-    uint32_t c = 0;
-    if ((len_mask >> L) & 1) {
-      c = hb[hp++];
-      if (c == 0 && nlen == 1) c = 256;  // 256 is stored as 0 (:724-728)
-    }
-    cnt[L] = c;
-    fcode[L] = cur;
-    soff[L] = nsym;
-    cur += c << (kMaxCodeLen - L);
-    nsym += c;
-  }
-  fcode[kMaxCodeLen + 1] = cur;
-  const uint32_t lead_raw_size = lead[0];
-  if (nsym > 256) lead_err = HFZ_E_CORRUPT;
-  if (nsym == 0 ? lead_raw_size != 0 : cur != (1u << kMaxCodeLen)) lead_err = HFZ_E_CORRUPT;
-  if (lead_err != HFZ_OK) {  // uniform over the workgroup: nobody waits at a barrier below
-    if (lane == 0 && status && present) status[f] = err != HFZ_OK ? err : lead_err;
-    return;
-  }
-  const uint8_t* const syms = hb + 8 + nlen;  // canonical symbol order
-
-  // this wave's own frame
-  const uint32_t raw_size = hdrw[0];
-  const uint64_t out_base = f * frame_bytes;
-  const uint32_t hdr_total = 8 + nlen + nsym + 4 * (K - 1);
-  if (err == HFZ_OK) {
-    uint64_t room = out_base <= raw_cap ? raw_cap - out_base : 0;
-    if (room > frame_bytes) room = frame_bytes;
-    if (raw_size > room) err = HFZ_E_CAPACITY;
-    if ((uint64_t)hdr_total + (uint64_t)kSlop * K > size) err = HFZ_E_CORRUPT;
-    if (nsym == 0 && raw_size != 0) err = HFZ_E_CORRUPT;
-    if (kWaves > 1) {
-      // same code section as the first frame, byte for byte: dwords 1.. up to 8 + nlen + nsym
-      const uint32_t code_end = 8 + nlen + nsym;
-      bool differs = false;
-      for (uint32_t i = 1 + lane; 4 * i < code_end; i += 64) {
-        uint32_t m = 0xffffffffu;
-        if (4 * i + 4 > code_end) m >>= 8 * (4 * i + 4 - code_end);
-        differs |= ((hdrw[i] ^ lead[i]) & m) != 0;
-      }
-      if (__any(differs) && err == HFZ_OK) err = HFZ_E_CODE_MISMATCH;
-    }
-  }
-
-  // stream boundaries (codec/huffman.cpp:897-901); lanes >= K get an empty stream
-  const uint32_t area_size = err == HFZ_OK ? size - hdr_total : 0;
-  uint32_t end = kSlop, begin = 0;
-  if (err == HFZ_OK) {
-    bool bad = false;
-    if (lane < K) {
-      const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
-      if (lane < K - 1) {
-        const uint32_t p = eo + 4 * lane;
-        end = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
+    for (uint32_t j = 0; j < 3; ++j) {
+      const uint32_t idx = lane + 64 * j;
+      uint32_t v = 0;
+      if (4 * idx + 4 <= size) {
+        v = load_u32u(p_in + 4 * idx);
       } else {
-        end = area_size;
+        for (uint32_t b = 0; b < 4; ++b)
+          if (4 * idx + b < size) v |= (uint32_t)p_in[4 * idx + b] << (8 * b);
       }
-      if (lane) {
-        const uint32_t p = eo + 4 * (lane - 1);
-        begin = __builtin_amdgcn_alignbyte(hdrw[(p >> 2) + 1], hdrw[p >> 2], p & 3);
-      }
-      bad = end > area_size || begin > end || end - begin < (uint32_t)kSlop;
+      hdrw[idx] = v;
     }
-    if (__any(bad)) err = HFZ_E_CORRUPT;
+    HFZ_BARRIER();
+
+    // The code section (len_mask, per-length counts, canonical symbol order) is
+    // read from the workgroup's first frame, which is this frame when kWaves = 1.
+    // ParseCompressedHeader (codec/huffman.cpp:714-736) + canonical code starts
+    // (ForallCodes, codec/huffman.cpp:260-284).
+    const uint32_t* const lead = ringmem + 64 * kDecInDw;
+    const uint8_t* const hb = (const uint8_t*)lead;
+    const uint32_t len_mask = lead[1];
+    const uint32_t nlen = __popc(len_mask);
+    int lead_err = HFZ_OK;
+    if ((len_mask >> (kMaxCodeLen + 1)) != 0) lead_err = HFZ_E_CORRUPT;
+    uint32_t cnt[kMaxCodeLen + 1], fcode[kMaxCodeLen + 2], soff[kMaxCodeLen + 1];
+    uint32_t cur = 0, nsym = 0, hp = 8;
+#pragma unroll
+    for (int L = 0; L <= kMaxCodeLen; ++L) {
+      uint32_t c = 0;
+      if ((len_mask >> L) & 1) {
+        c = hb[hp++];
+        if (c == 0 && nlen == 1) c = 256;  // 256 is stored as 0 (:724-728)
+      }
+      cnt[L] = c;
+      fcode[L] = cur;
+      soff[L] = nsym;
+      cur += c << (kMaxCodeLen - L);
+      nsym += c;
+    }
+    fcode[kMaxCodeLen + 1] = cur;
+    const uint32_t lead_raw_size = lead[0];
+    if (nsym > 256) lead_err = HFZ_E_CORRUPT;
+    if (nsym == 0 ? lead_raw_size != 0 : cur != (1u << kMaxCodeLen)) lead_err = HFZ_E_CORRUPT;
+    if (kF == 1 && lead_err != HFZ_OK) {  // uniform over the workgroup: nobody waits at a barrier below
+      if (lane == 0 && status && p_present) status[pf] = p_err != HFZ_OK ? p_err : lead_err;
+      return;
+    }
+    if (p_err == HFZ_OK) p_err = lead_err;
+    const uint8_t* const syms = hb + 8 + nlen;  // canonical symbol order
+
+    // this frame's own numbers
+    const uint32_t p_raw_size = hdrw[0];
+    const uint32_t p_hdr_total = 8 + nlen + nsym + 4 * (K - 1);
+    if (p_err == HFZ_OK) {
+      const uint64_t p_out = pf * frame_bytes;
+      uint64_t room = p_out <= raw_cap ? raw_cap - p_out : 0;
+      if (room > frame_bytes) room = frame_bytes;
+      if (p_raw_size > room) p_err = HFZ_E_CAPACITY;
+      if ((uint64_t)p_hdr_total + (uint64_t)kSlop * K > size) p_err = HFZ_E_CORRUPT;
+      if (nsym == 0 && p_raw_size != 0) p_err = HFZ_E_CORRUPT;
+      if (kWaves > 1) {
+        // same code section as the first frame, byte for byte: dwords 1.. up to 8 + nlen + nsym
+        const uint32_t code_end = 8 + nlen + nsym;
+        bool differs = false;
+        for (uint32_t i = 1 + lane; 4 * i < code_end; i += 64) {
+          uint32_t m = 0xffffffffu;
+          if (4 * i + 4 > code_end) m >>= 8 * (4 * i + 4 - code_end);
+          differs |= ((hdrw[i] ^ lead[i]) & m) != 0;
+        }
+        if (__any(differs) && p_err == HFZ_OK) p_err = HFZ_E_CODE_MISMATCH;
+      }
+    }
+
+    // stream boundaries (codec/huffman.cpp:897-901); lanes without a stream get an empty one
+    const uint32_t area_size = p_err == HFZ_OK ? size - p_hdr_total : 0;
+    uint32_t p_end = kSlop;
+    if (p_err == HFZ_OK) {
+      bool bad = false;
+      if (mine && k < K) {
+        uint32_t begin = 0;
+        const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
+        if (k < K - 1) {
+          const uint32_t q = eo + 4 * k;
+          p_end = __builtin_amdgcn_alignbyte(hdrw[(q >> 2) + 1], hdrw[q >> 2], q & 3);
+        } else {
+          p_end = area_size;
+        }
+        if (k) {
+          const uint32_t q = eo + 4 * (k - 1);
+          begin = __builtin_amdgcn_alignbyte(hdrw[(q >> 2) + 1], hdrw[q >> 2], q & 3);
+        }
+        bad = p_end > area_size || begin > p_end || p_end - begin < (uint32_t)kSlop;
+      }
+      if (__any(bad)) p_err = HFZ_E_CORRUPT;
+    }
+    if (kWaves == 1 && kF == 1 && p_err != HFZ_OK) {
+      if (lane == 0 && status && p_present) status[pf] = p_err;
+      return;
+    }
+    if (mine) {
+      f = pf;
+      present = p_present;
+      err = p_err;
+      in = p_in;
+      raw_size = p_raw_size;
+      hdr_total = p_hdr_total;
+      end = p_end;
+    }
+    STAMP(0);  // header
+
+    // single-symbol entries, one code-length class at a time; table indices are
+    // the top kDecTabBits bits of the left-aligned 12-bit code space
+    uint32_t* const ptab = tab + (pass << kDecTabBits);
+    constexpr uint32_t kTabShift = (uint32_t)kMaxCodeLen - kDecTabBits;
+    static_assert(kTabShift <= 1, "escape entries cover one bit");
+    if (kF == 1 || p_err == HFZ_OK) {
+#pragma unroll
+      for (uint32_t L = 0; L <= kDecTabBits; ++L) {
+        if (cnt[L] == 0) continue;
+        const uint32_t lo = fcode[L] >> kTabShift, hi = fcode[L + 1] >> kTabShift;
+#pragma unroll 4
+        for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
+          const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
+          ptab[e] = L | ((uint32_t)syms[j] << 8) | (8u << 24);
+          l1tab[e] = (uint8_t)L;
+        }
+      }
+      if (kTabShift) {  // sibling pairs of 12-bit codes (their count is even: the code is complete)
+        const uint32_t lo = fcode[kMaxCodeLen] >> 1;
+        for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
+          const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
+          ptab[e] = kDecEsc | (uint32_t)kMaxCodeLen | ((uint32_t)syms[j] << 8) |
+                    ((uint32_t)syms[j + 1] << 16) | (8u << 24);
+          l1tab[e] = (uint8_t)kMaxCodeLen;
+        }
+      }
+    }
+    HFZ_BARRIER();
+    // second symbol where both codes fit in the index bits.  Byte 1 of an entry
+    // and l1tab never change in this pass, so reading another lane's entry while
+    // it is being rewritten is safe.
+    if (kF == 1 || p_err == HFZ_OK) {
+#pragma unroll 8
+      for (uint32_t e = tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
+        const uint32_t L1 = l1tab[e];
+        const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
+        const uint32_t L2 = l1tab[rem];
+        if (L1 + L2 <= kDecTabBits)
+          ptab[e] = (L1 + L2) | (ptab[e] & 0xff00) | ((ptab[rem] & 0xff00) << 8) | (16u << 24);
+      }
+    }
+    HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
+    STAMP(1);  // table
   }
-  if (kWaves == 1 && err != HFZ_OK) {
-    if (lane == 0 && status && present) status[f] = err;
+#undef HFZ_BARRIER
+  if ((kWaves > 1 || kF > 1) && (err != HFZ_OK || !present)) {  // past the last barrier: lanes part ways
+    if (k == 0 && status && present) status[f] = err;
     return;
   }
-  STAMP(0);  // header
-
-  // single-symbol entries, one code-length class at a time; table indices are
-  // the top kDecTabBits bits of the left-aligned 12-bit code space
-  constexpr uint32_t kTabShift = (uint32_t)kMaxCodeLen - kDecTabBits;
-  static_assert(kTabShift <= 1, "escape entries cover one bit");
-#pragma unroll
-  for (uint32_t L = 0; L <= kDecTabBits; ++L) {
-    if (cnt[L] == 0) continue;
-    const uint32_t lo = fcode[L] >> kTabShift, hi = fcode[L + 1] >> kTabShift;
-#pragma unroll 4
-    for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
-      const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
-      tab[e] = L | ((uint32_t)syms[j] << 8) | (8u << 24);
-      l1tab[e] = (uint8_t)L;
-    }
-  }
-  if (kTabShift) {  // sibling pairs of 12-bit codes (their count is even: the code is complete)
-    const uint32_t lo = fcode[kMaxCodeLen] >> 1;
-    for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
-      const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
-      tab[e] = kDecEsc | (uint32_t)kMaxCodeLen | ((uint32_t)syms[j] << 8) |
-               ((uint32_t)syms[j + 1] << 16) | (8u << 24);
-      l1tab[e] = (uint8_t)kMaxCodeLen;
-    }
-  }
-  HFZ_BARRIER();
-  // second symbol where both codes fit in the index bits.  Byte 1 of an entry
-  // and l1tab never change in this pass, so reading another lane's entry while
-  // it is being rewritten is safe.
-#pragma unroll 8
-  for (uint32_t e = tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
-    const uint32_t L1 = l1tab[e];
-    const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
-    const uint32_t L2 = l1tab[rem];
-    if (L1 + L2 <= kDecTabBits)
-      tab[e] = (L1 + L2) | (tab[e] & 0xff00) | ((tab[rem] & 0xff00) << 8) | (16u << 24);
-  }
-  STAMP(1);  // table
+  const uint32_t* const mytab = tab + (half << kDecTabBits);
 
   // Input side: offsets are relative to cbase, a 64-byte aligned address 256
   // bytes below the frame, so that the block arithmetic below (up to three
@@ -1393,23 +1433,17 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   const uint32_t g_end = area_off + end;  // one past the stream's last byte
   // Output side: offsets relative to obase, the 32-byte block holding the
   // frame's first output byte.
-  uint8_t* const frame_out = raw + out_base;
+  uint8_t* const frame_out = raw + f * frame_bytes;
   uint8_t* const obase = frame_out - ((uintptr_t)frame_out & 31);
   Slice s;
   s.begin = 0;
   s.size = 0;
-  if (lane < K) s = slice_of(raw_size, K, lane);
+  if (k < K) s = slice_of(raw_size, K, k);
   const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
   const uint32_t out_hi = out_lo + s.size;
 
   uint32_t* const irow = iring + lane;      // dword d of this lane's input ring: irow[64 * d]
   uint32_t* const orow32 = obuf_all + lane;  // dword d of its output ring: orow32[64 * d]
-  HFZ_BARRIER();  // table complete; the scratch aliased on the rings is dead
-#undef HFZ_BARRIER
-  if (kWaves > 1 && (err != HFZ_OK || !present)) {  // past the last barrier: waves part ways
-    if (lane == 0 && status && present) status[f] = err;
-    return;
-  }
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
   uint4 pre[4];
@@ -1500,7 +1534,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   } while (0)
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
-    uint32_t e_ = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];             \
+    uint32_t e_ = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];             \
     /* the compiler turns this into a select (9 VALU); a forced branch      \
        measured 3-8 % slower */                                             \
     if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e_ < 0)              \
@@ -1572,7 +1606,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
           const uint32_t wa_b = wa;
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-            uint32_t e = tab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
+            uint32_t e = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
             if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e < 0) e = resolve_escape(e, bitbuf);
             uint32_t ns = e >> 27;
             uint32_t pair = (e >> 8) & 0xffff;
@@ -1625,8 +1659,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   STAMP(7);  // tail
   STAMP_FLUSH(0);
   if (status) {
-    const bool any_bad = __any(stream_bad);
-    if (lane == 0) status[f] = any_bad ? HFZ_E_CORRUPT : HFZ_OK;
+    const uint64_t bad_lanes = __ballot(stream_bad);
+    const bool any_bad = kF == 1 ? bad_lanes != 0 : ((bad_lanes >> (32 * half)) & 0xffffffffull) != 0;
+    if (k == 0) status[f] = any_bad ? HFZ_E_CORRUPT : HFZ_OK;
   }
 }
 
@@ -1684,6 +1719,7 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 }  // namespace
 
 int g_decoder_table_bits = 0;
+int g_frames_per_wave = 0;
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -1758,6 +1794,13 @@ int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t co
   return hipGetLastError();
 }
 
+int device_cus();
+// two frames per wave once the pairs still give every SIMD a wave
+bool pair_frames(int K, uint64_t n_frames) {
+  if (K > 32 || g_frames_per_wave == 1) return false;
+  return g_frames_per_wave == 2 || n_frames > 4 * (uint64_t)device_cus();
+}
+
 int device_cus() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
@@ -1772,8 +1815,7 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
                   const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  // two frames per wave once the pairs still give every SIMD a wave
-  if (K <= 32 && n_frames > 4 * (uint64_t)device_cus())
+  if (pair_frames(K, n_frames))
     hipLaunchKernelGGL(encode_kernel<2>, dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames, d_code,
                        shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size, d_comp,
@@ -1798,7 +1840,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
     // LDS, three workgroups (nine frames) per CU and no escape entries
     const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
-    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves>), dim3((uint32_t)groups),
+    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves, 1>), dim3((uint32_t)groups),
                        dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
                        comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
                        d_status);
@@ -1808,13 +1850,20 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
   // costs less than the extra resident waves return.
   const int cus = device_cus();
+  if (g_decoder_table_bits != 12 && pair_frames(K, n_frames)) {
+    // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
+    hipLaunchKernelGGL((decode_kernel<11, 1, 2>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
+                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    return hipGetLastError();
+  }
   const bool wide = g_decoder_table_bits ? g_decoder_table_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
-    hipLaunchKernelGGL((decode_kernel<12, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
+    hipLaunchKernelGGL((decode_kernel<12, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   else
-    hipLaunchKernelGGL((decode_kernel<11, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
+    hipLaunchKernelGGL((decode_kernel<11, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   return hipGetLastError();

@@ -219,6 +219,15 @@ int hfz_timing_read(hfz_batch_timing* out);
 int hfz_set_decoder_table_bits(int bits);
 
 /*
+ * With K <= 32 one frame fills at most half a wavefront, so the encoder and the
+ * decoder can give each half of a wave a frame of its own.  n = 0 (default)
+ * does so when the batch has enough frames to keep the chip busy either way,
+ * 1 never, 2 always (K <= 32 only).  Output is identical.  Process-wide; has no
+ * counterpart in the reference.
+ */
+int hfz_set_frames_per_wave(int n);
+
+/*
  * Deterministic integer-only synthetic source, filled on the device:
  * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
  * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).

@@ -418,3 +418,55 @@ def test_shared_decoder_refuses_mixed_codes(torch_cuda):
             assert st[i] in (0, hfz.HFZ_E_CODE_MISMATCH)
             if st[i] == 0:
                 assert torch.equal(out[i * frame_bytes:(i + 1) * frame_bytes], parts[i])
+
+
+# ---- two frames per wave (K <= 32) -------------------------------------------
+
+def test_two_frames_per_wave(torch_cuda):
+    # forced on small batches: every K <= 32, odd frame counts, ragged last frame,
+    # frames smaller than K, and a corrupt frame next to a good one in the same wave
+    torch = torch_cuda
+    hfz.set_frames_per_wave(2)
+    try:
+        for K, total, frame_bytes in [(32, 7 * 50000 + 1234, 50000), (16, 300000, 100000),
+                                      (7, 5 * 4096, 4096), (1, 3 * 3000, 3000), (32, 100, 40),
+                                      (24, 2 * 70000, 70000), (4, 9 * 25600, 25600)]:
+            raw = hfz.generate(geometric_cdf(), K * 7 + 1, total)
+            host = raw.cpu().numpy().tobytes()
+            codec = hfz.BatchCodec(K, total, frame_bytes)
+            batch = codec.compress(raw)
+            out = codec.decompress(batch)
+            torch.cuda.synchronize()
+            assert int(codec.status.abs().sum().item()) == 0
+            assert int(codec.dstatus.abs().sum().item()) == 0
+            assert out.cpu().numpy().tobytes() == host, (K, total)
+            for i in range(codec.n_frames):
+                assert batch.frame_bytes_host(i) == oracle.compress(
+                    K, host[i * frame_bytes:(i + 1) * frame_bytes]), (K, i)
+        # oracle frames, one of each pair broken
+        K, frame_bytes = 32, 30000
+        raw = load_input("long_random.bin")[:4 * frame_bytes]
+        frames = [bytearray(oracle.compress(K, raw[i:i + frame_bytes]))
+                  for i in range(0, len(raw), frame_bytes)]
+        frames[1][8] += 1          # Kraft sum broken in the second frame of wave 0
+        frames[2] = frames[2][:20]  # truncated first frame of wave 1
+        blob, offs = bytearray(), []
+        for fr in frames:
+            offs.append(len(blob))
+            blob += fr
+        comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8), device="cuda")
+        d_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        d_size = torch.tensor([len(f) for f in frames], dtype=torch.int32, device="cuda")
+        out = torch.zeros(len(raw), dtype=torch.uint8, device="cuda")
+        status = torch.full((len(frames),), 77, dtype=torch.int32, device="cuda")
+        rc = hfz.lib().hfz_decompress_batch_dev(K, comp.data_ptr(), comp.numel(), d_off.data_ptr(),
+                                                d_size.data_ptr(), len(frames), out.data_ptr(),
+                                                len(raw), frame_bytes, status.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [0, hfz.HFZ_E_CORRUPT, hfz.HFZ_E_CORRUPT, 0]
+        got = out.cpu().numpy().tobytes()
+        assert got[:frame_bytes] == raw[:frame_bytes]
+        assert got[3 * frame_bytes:] == raw[3 * frame_bytes:]
+    finally:
+        hfz.set_frames_per_wave(0)

@@ -12,6 +12,10 @@ def child(lib, cfgs):
     hfz = importlib.import_module("huffman-avx512_amd")
     hfz.LIB_PATH = os.path.abspath(lib)
     hfz.lib()
+    if os.environ.get("HFZ_FPW"):
+        hfz.set_frames_per_wave(int(os.environ["HFZ_FPW"]))
+    if os.environ.get("HFZ_BITS"):
+        hfz.set_decoder_table_bits(int(os.environ["HFZ_BITS"]))
     for cfg in cfgs:
         K, mib, fk, src = cfg.split(":")
         K, total, fb = int(K), int(mib) << 20, int(fk) << 10
