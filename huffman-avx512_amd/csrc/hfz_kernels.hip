@@ -663,12 +663,14 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
 //
 // One workgroup of 256 threads per frame.  Thread t counts part t / K of
 // stream t % K.  The counters form 256 rows (one per byte value) of 32 words:
-//   K > 32 : word = stream / 2, a 16-bit count per stream (slices of at most
-//            65535 bytes; the launcher falls back to hist_kernel + sizes_kernel
-//            beyond that)
+//   K > 32 : word = stream % 32, 16-bit count number stream / 32 in it (slices of
+//            at most 65535 bytes; the launcher falls back to hist_kernel +
+//            sizes_kernel beyond that)
 //   K <= 32: word = stream + K * (part % (32 / K)), a 32-bit count
-// Consecutive lanes count different streams, so the 64 lanes of an LDS atomic
-// always fall on 32 different banks whatever the data looks like.
+// Lanes l and l + 32 of a wave share a word (or, with K <= 32, at least a
+// bank) and all other lanes are on other banks: each half of an LDS atomic
+// hits 32 different banks whatever the data looks like.  The kernel ends up
+// limited by its reads (every lane walks its own kilobyte: about 3.6 TB/s).
 constexpr uint32_t kCntThreads = 256;
 constexpr uint32_t kCntBlk = 128;  // bytes per lane per load group (the next group is in flight)
 
@@ -750,8 +752,8 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
       const uint8_t* const frame_in = raw + f * frame_bytes;
       const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & (kCntBlk - 1));
       const uint32_t in0 = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
-      const uint32_t colidx = packed ? stream >> 1 : stream + K * (part % reps);
-      const uint32_t inc = packed ? 1u << (16 * (stream & 1)) : 1u;
+      const uint32_t colidx = packed ? stream & 31 : stream + K * (part % reps);
+      const uint32_t inc = packed ? 1u << (16 * (stream >> 5)) : 1u;
       count_range(ibase, in0 + rel_lo, in0 + rel_hi, cnt + colidx, inc);
     }
   }
@@ -785,8 +787,8 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
   {
     uint32_t bits = 0;
     if (lane < K) {
-      const uint32_t sh = packed ? 16 * (lane & 1) : 0;
-      const uint32_t c0 = packed ? lane >> 1 : lane;
+      const uint32_t sh = packed ? 16 * (lane >> 5) : 0;
+      const uint32_t c0 = packed ? lane & 31 : lane;
       for (uint32_t q = 0; q < 16; ++q) {
         const uint32_t sym0 = wave * 64 + 4 * q;
         const uint32_t l4 = lens4[sym0 >> 2];
@@ -867,8 +869,8 @@ __global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32
     }
   }
   if (packed) {
-    atomicAdd(&sums[2 * col], acc_lo);
-    atomicAdd(&sums[2 * col + 1], acc_hi);
+    atomicAdd(&sums[col], acc_lo);
+    atomicAdd(&sums[col + 32], acc_hi);
   } else if (col < K * reps) {
     atomicAdd(&sums[col % K], acc_lo);
   }
