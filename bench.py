@@ -82,19 +82,14 @@ def main():
     out = torch.empty(total, dtype=torch.uint8, device=dev)
 
     L = hfz.lib()
-    hist32 = torch.zeros(256, dtype=torch.int32, device=dev)
     code = torch.zeros(792, dtype=torch.uint8, device=dev)
 
     def shared_code():
-        # byte counts of this rank's batch (pieces of 2 GiB: 32-bit counters), summed
-        # over ranks: the job's one exchange, 2 KiB per GPU
+        # one pass over the batch leaves per-stream counts in the workspace and the
+        # 256 byte counts here; those are summed over ranks: the job's one exchange,
+        # 2 KiB per GPU
         st = torch.cuda.current_stream(dev).cuda_stream
-        h = torch.zeros(256, dtype=torch.int64, device=dev)
-        for lo in range(0, total, 1 << 31):
-            part = raw[lo:lo + (1 << 31)]
-            rc = L.hfz_histogram_dev(part.data_ptr(), part.numel(), hist32.data_ptr(), st)
-            assert rc == 0, rc
-            h += hist32.to(torch.int64) & 0xffffffff
+        h = codec.count(raw).clone()
         if world > 1:
             dist.all_reduce(h)
         # counts beyond 32 bits are scaled down, every occurring symbol stays nonzero
@@ -107,7 +102,7 @@ def main():
 
     def step():
         if args.shared_table:
-            batch = codec.compress(raw, code=shared_code())
+            batch = codec.compress(raw, code=shared_code(), counted=True)
             codec.decompress(batch, out, shared=True)
         else:
             batch = codec.compress(raw)

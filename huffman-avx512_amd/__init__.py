@@ -38,6 +38,7 @@ EXPORTS = (
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
     "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
     "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
+    "hfz_count_batch_dev", "hfz_compress_batch_counted_dev",
 )
 
 
@@ -117,6 +118,10 @@ def lib():
         L.hfz_compress_batch_shared_dev.argtypes = [ci, vp, sz, sz, vp, vp, sz, sz, vp, vp, vp, vp, sz, vp]
         L.hfz_decompress_batch_shared_dev.restype = ci
         L.hfz_decompress_batch_shared_dev.argtypes = [ci, vp, sz, vp, vp, sz, vp, sz, sz, vp, vp]
+        L.hfz_count_batch_dev.restype = ci
+        L.hfz_count_batch_dev.argtypes = [ci, vp, sz, sz, vp, sz, vp, vp]
+        L.hfz_compress_batch_counted_dev.restype = ci
+        L.hfz_compress_batch_counted_dev.argtypes = [ci, vp, sz, sz, vp, vp, sz, sz, vp, vp, vp, vp, sz, vp]
         L.hfz_histogram_dev.restype = ci
         L.hfz_histogram_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_histogram_batch_dev.restype = ci
@@ -327,11 +332,27 @@ class BatchCodec:
         host = torch.frombuffer(bytearray(bytes(fc)), dtype=torch.uint8)
         return host.to(self.device)
 
-    def compress(self, raw, code=None):
+    def count(self, raw):
+        """First half of the two-step shared-code encoder: one pass over `raw` that
+        leaves per-stream counts in the workspace; returns the batch's 256 byte
+        counts as a device int64 tensor (sum them over ranks, build the code, then
+        compress(raw, code=..., counted=True))."""
+        torch = self.torch
+        assert raw.dtype == torch.uint8 and raw.numel() == self.total and raw.is_cuda
+        if not hasattr(self, "hist_total"):
+            self.hist_total = torch.zeros(256, dtype=torch.int64, device=self.device)
+        _check(lib().hfz_count_batch_dev(self.K, raw.data_ptr(), self.total, self.frame_bytes,
+                                         self.ws.data_ptr(), self.ws_bytes,
+                                         self.hist_total.data_ptr(), self._stream()),
+               "hfz_count_batch_dev")
+        return self.hist_total
+
+    def compress(self, raw, code=None, counted=False):
         assert raw.dtype == self.torch.uint8 and raw.numel() == self.total and raw.is_cuda
         if code is not None:
             assert code.is_cuda and code.numel() == ctypes.sizeof(FrameCode)
-            _check(lib().hfz_compress_batch_shared_dev(
+            fn = lib().hfz_compress_batch_counted_dev if counted else lib().hfz_compress_batch_shared_dev
+            _check(fn(
                 self.K, raw.data_ptr(), self.total, self.frame_bytes, code.data_ptr(),
                 self.comp.data_ptr(), self.comp_cap, self.stride, self.comp_off.data_ptr(),
                 self.comp_size.data_ptr(), self.status.data_ptr(), self.ws.data_ptr(),

@@ -285,7 +285,9 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
                          shared ? nullptr : d_counts, shared ? nullptr : d_hist, d_send, d_csize,
                          stream));
     HFZ_HIP(mark(1, st));
-    if (!shared) HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, d_send, d_csize, stream));
+    if (!shared)
+      HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, nullptr, false, d_send, d_csize,
+                                stream));
     HFZ_HIP(mark(2, st));
   } else {
     if (!shared) HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
@@ -332,6 +334,68 @@ int hfz_compress_batch_dev(int K, const void* d_raw, size_t total, size_t frame_
                            void* d_ws, size_t ws_bytes, void* stream) {
   return compress_batch(K, d_raw, total, frame_bytes, d_comp, comp_cap, comp_stride, d_comp_off,
                         d_comp_size, d_status, d_ws, ws_bytes, nullptr, stream);
+}
+
+int hfz_count_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes, void* d_ws,
+                        size_t ws_bytes, uint64_t* d_hist_total, void* stream) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || frame_bytes == 0 || !d_ws || !d_hist_total || (total && !d_raw))
+    return HFZ_E_ARG;
+  if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  const size_t nf = hfz_batch_frames(total, frame_bytes);
+  const WorkspaceLayout w = workspace_layout(nf);
+  if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
+  uint8_t* ws = (uint8_t*)d_ws;
+  uint32_t* d_hist = (uint32_t*)(ws + w.hist);
+  const uint8_t* raw = (const uint8_t*)d_raw;
+  if (count_kernel_fits(K, frame_bytes)) {
+    HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, false, (uint32_t*)(ws + w.counts),
+                         d_hist, (uint32_t*)(ws + w.stream_end), (uint32_t*)(ws + w.csize), stream));
+  } else {
+    HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+  }
+  HFZ_HIP(launch_hist_total(d_hist, nf, d_hist_total, stream));
+  return HFZ_OK;
+}
+
+int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                                   const hfz_frame_code* d_code, void* d_comp, size_t comp_cap,
+                                   size_t comp_stride, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                                   int32_t* d_status, void* d_ws, size_t ws_bytes, void* stream) {
+  if (K < 1 || K > HFZ_MAX_STREAMS || frame_bytes == 0 || !d_comp || !d_comp_off || !d_comp_size ||
+      !d_ws || !d_code || (total && !d_raw))
+    return HFZ_E_ARG;
+  if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
+  if (comp_stride && comp_stride < hfz_compress_bound(frame_bytes, K)) return HFZ_E_ARG;
+  const size_t nf = hfz_batch_frames(total, frame_bytes);
+  const WorkspaceLayout w = workspace_layout(nf);
+  if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
+  uint8_t* ws = (uint8_t*)d_ws;
+  uint32_t* d_send = (uint32_t*)(ws + w.stream_end);
+  uint32_t* d_csize = (uint32_t*)(ws + w.csize);
+  const FrameCode* code = (const FrameCode*)d_code;
+  const uint8_t* raw = (const uint8_t*)d_raw;
+  hipStream_t st = (hipStream_t)stream;
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
+  HFZ_HIP(mark(0, st));
+  HFZ_HIP(mark(1, st));  // the input pass was hfz_count_batch_dev
+  if (count_kernel_fits(K, frame_bytes)) {
+    HFZ_HIP(launch_code_sizes(K, nullptr, (const uint32_t*)(ws + w.counts), nf, nullptr, code, true,
+                              d_send, d_csize, stream));
+    HFZ_HIP(mark(2, st));
+  } else {
+    HFZ_HIP(mark(2, st));
+    HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, nullptr, const_cast<FrameCode*>(code),
+                                true, d_send, d_csize, stream));
+  }
+  HFZ_HIP(mark(3, st));
+  HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
+                               d_status, stream));
+  HFZ_HIP(mark(4, st));
+  HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, code, true, d_send, d_comp_off,
+                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream));
+  HFZ_HIP(mark(5, st));
+  g_timing.cur = nullptr;
+  return HFZ_OK;
 }
 
 int hfz_compress_batch_shared_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,

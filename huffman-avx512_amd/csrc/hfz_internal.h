@@ -80,8 +80,12 @@ int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_byt
                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                  uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
                  uint32_t* d_csize, void* stream);
+// d_given == nullptr: builds d_code[f] from d_hist[f]; otherwise no code is built and the
+// sizes are those under d_given (per frame, or one for all with shared_code).
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
-                      FrameCode* d_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+                      FrameCode* d_code, const FrameCode* d_given, bool shared_code,
+                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream);
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
                          int32_t* d_status, void* stream);

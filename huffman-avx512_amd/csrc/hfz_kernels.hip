@@ -826,9 +826,12 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
 // its histogram (build_code), then the coded size of every stream from the
 // per-stream counts count_kernel left in memory (same layout as its LDS array).
 // Lane l walks the rows of parity l / 32 and owns counter word l % 32.
+// given != null: no code is built; the sizes are those under given[f * given_step].
 __global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ counts,
                                                         FrameCode* __restrict__ code,
+                                                        const FrameCode* __restrict__ given,
+                                                        uint32_t given_step,
                                                         uint32_t* __restrict__ stream_end,
                                                         uint32_t* __restrict__ csize) {
   __shared__ uint32_t lens[256];
@@ -841,10 +844,19 @@ __global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32
   uint32_t nxt[kAhead];
 #pragma unroll
   for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * i];
-  const uint16_t* encs = build_code(hist + f * 256, code + f, lane);
-  for (uint32_t i = lane; i < 256; i += 64) lens[i] = encs[i] & 15;
+  uint32_t hdr_len;
+  if (given) {
+    const FrameCode& fc = given[f * given_step];
+    for (uint32_t i = lane; i < 256; i += 64) lens[i] = fc.enc[i] & 15;
+    hdr_len = fc.hdr_len;
+  } else {
+    const uint16_t* encs = build_code(hist + f * 256, code + f, lane);
+    for (uint32_t i = lane; i < 256; i += 64) lens[i] = encs[i] & 15;
+    hdr_len = 0;  // read back below, after the barrier
+  }
   sums[lane] = 0;
   wave_sync();
+  if (!given) hdr_len = code[f].hdr_len;  // written by lane 0 of this wave inside build_code
   const bool packed = K > 32;
   const uint32_t reps = packed ? 1 : 32 / K;
   const uint32_t col = lane & 31, par = lane >> 5;
@@ -879,8 +891,17 @@ __global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32
   if (lane < K) bytes = (sums[lane] + 7) / 8 + kSlop;
   const uint32_t incl = wave_inclusive_scan(bytes, lane);
   if (lane < K) stream_end[f * 64 + lane] = incl;
-  // hdr_len was written by lane 0 of this wave inside build_code
-  if (lane == K - 1) csize[f] = 4 + code[f].hdr_len + 4 * (K - 1) + incl;
+  if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl;
+}
+
+// Sum of the per-frame histograms of a batch, 64-bit: total[c] = sum over f of hist[f][c].
+__global__ __launch_bounds__(256) void hist_total_kernel(const uint32_t* __restrict__ hist,
+                                                         uint64_t n_frames,
+                                                         unsigned long long* __restrict__ total) {
+  const uint32_t c = threadIdx.x;
+  unsigned long long sum = 0;
+  for (uint64_t f = blockIdx.x; f < n_frames; f += gridDim.x) sum += hist[f * 256 + c];
+  if (sum) atomicAdd(&total[c], sum);
 }
 
 // ---------------------------------------------------------------------------
@@ -1779,11 +1800,22 @@ int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_byt
 }
 
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
-                      FrameCode* d_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+                      FrameCode* d_code, const FrameCode* d_given, bool shared_code,
+                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_hist, d_counts, d_code, d_stream_end, d_csize);
+                     (uint32_t)K, d_hist, d_counts, d_code, d_given, shared_code ? 0u : 1u,
+                     d_stream_end, d_csize);
+  return hipGetLastError();
+}
+
+int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream) {
+  hipError_t e = hipMemsetAsync(d_total, 0, 256 * sizeof(uint64_t), as_stream(stream));
+  if (e != hipSuccess || n_frames == 0) return e;
+  const uint32_t blocks = n_frames < 1024 ? (uint32_t)n_frames : 1024u;
+  hipLaunchKernelGGL(hist_total_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_hist,
+                     n_frames, (unsigned long long*)d_total);
   return hipGetLastError();
 }
 
@@ -1831,6 +1863,7 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
 }
 
 constexpr uint32_t kSharedWaves = 3;  // frames per workgroup when they share one code
+constexpr uint64_t kSharedMaxFrame = 128u << 10;
 
 
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
@@ -1838,9 +1871,12 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
                   uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  if (shared_code) {
+  if (shared_code && frame_bytes <= kSharedMaxFrame) {
     // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
-    // LDS, three workgroups (nine frames) per CU and no escape entries
+    // LDS, three workgroups (nine frames) per CU and no escape entries.  Pays
+    // off while building a table is a visible part of a frame's work; larger
+    // frames go through the per-frame kernels below, which are faster there
+    // (one-wave workgroups pack the CUs better) and decode any frame.
     const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
     hipLaunchKernelGGL((decode_kernel<12, kSharedWaves, 1>), dim3((uint32_t)groups),
                        dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,

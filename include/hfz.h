@@ -169,11 +169,30 @@ int hfz_compress_batch_shared_dev(int K, const void* d_raw, size_t total, size_t
                                   int32_t* d_status, void* d_ws, size_t ws_bytes, void* stream);
 
 /*
- * Decoder for batches whose frames share one code: groups of three consecutive
- * frames build one lookup table (from the first frame of the group) instead of
- * three.  A frame whose code section differs from its group's first frame gets
- * HFZ_E_CODE_MISMATCH in d_status and is left undecoded; hfz_decompress_batch_dev
- * decodes any batch.  Arguments as hfz_decompress_batch_dev.
+ * The same in two steps, so that the input is read twice instead of three
+ * times (histogram, sizes, encode): hfz_count_batch_dev makes one pass that
+ * leaves per-stream byte counts in the workspace and the batch's 256 byte
+ * counts (64-bit) in d_hist_total; after the code has been built from those
+ * (summed over GPUs where the job has several), hfz_compress_batch_counted_dev
+ * turns the counts into stream sizes and encodes.  Both calls must see the same
+ * K, d_raw, total, frame_bytes and workspace, with no other call on that
+ * workspace in between.  No counterpart in the reference.
+ */
+int hfz_count_batch_dev(int K, const void* d_raw, size_t total, size_t frame_bytes, void* d_ws,
+                        size_t ws_bytes, uint64_t* d_hist_total, void* stream);
+int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                                   const hfz_frame_code* d_code, void* d_comp, size_t comp_cap,
+                                   size_t comp_stride, uint64_t* d_comp_off, uint32_t* d_comp_size,
+                                   int32_t* d_status, void* d_ws, size_t ws_bytes, void* stream);
+
+/*
+ * Decoder for batches whose frames share one code.  With frames of up to
+ * 128 KiB, groups of three consecutive frames build one lookup table (from the
+ * first frame of the group) instead of three; a frame whose code section
+ * differs from its group's first frame then gets HFZ_E_CODE_MISMATCH in d_status
+ * and is left undecoded.  Larger frames take the same path as
+ * hfz_decompress_batch_dev (a table per frame costs nothing measurable there),
+ * which decodes any batch.  Arguments as hfz_decompress_batch_dev.
  */
 int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes,
                                     const uint64_t* d_comp_off, const uint32_t* d_comp_size,

@@ -383,6 +383,15 @@ def test_shared_code_batches(torch_cuda, K, total, frame_bytes, source):
         fr = batch.frame_bytes_host(i)
         assert oracle.decompress(K, fr) == chunk, i
         assert fr == oracle.compress_with_coding(K, coding, chunk), i
+    # the two-step encoder (count pass, then encode from the counts) writes the same frames
+    one_step = [batch.frame_bytes_host(i) for i in range(codec.n_frames)]
+    total_hist = codec.count(raw)
+    torch.cuda.synchronize()
+    assert total_hist.cpu().tolist() == hist.tolist()
+    batch2 = codec.compress(raw, code=code, counted=True)
+    torch.cuda.synchronize()
+    assert int(codec.status.abs().sum().item()) == 0
+    assert [batch2.frame_bytes_host(i) for i in range(codec.n_frames)] == one_step
     # both decoders take such a batch
     for shared in (True, False):
         out = codec.decompress(batch, shared=shared)
