@@ -479,3 +479,52 @@ def test_two_frames_per_wave(torch_cuda):
         assert got[3 * frame_bytes:] == raw[3 * frame_bytes:]
     finally:
         hfz.set_frames_per_wave(0)
+
+
+# ---- file container + command-line tool ---------------------------------------
+
+def _read_container(blob):
+    assert blob[:4] == b"HFZC" and int.from_bytes(blob[4:8], "little") == 1
+    K = int.from_bytes(blob[8:12], "little")
+    frame_bytes = int.from_bytes(blob[12:16], "little")
+    raw_bytes = int.from_bytes(blob[16:24], "little")
+    n_frames = int.from_bytes(blob[24:32], "little")
+    sizes = [int.from_bytes(blob[32 + 4 * i:36 + 4 * i], "little") for i in range(n_frames)]
+    pos = 32 + 4 * n_frames
+    frames = []
+    for sz in sizes:
+        frames.append(blob[pos:pos + sz])
+        pos += sz
+    assert pos == len(blob)
+    return K, frame_bytes, raw_bytes, frames
+
+
+def test_command_line_tool_round_trip(torch_cuda, tmp_path):
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(hfz.__file__)), "hfz")
+    assert os.path.exists(tool), "run __graft_entry__.build() first"
+    raw = load_input("long_random.bin") * 3 + load_input("lorem.bin")
+    src, packed, back = tmp_path / "in.bin", tmp_path / "in.hfz", tmp_path / "out.bin"
+    src.write_bytes(raw)
+    # frames of 64 KiB, batches of 1 MiB: several batches, a ragged last frame
+    subprocess.run([tool, "c", "-k", "32", "-f", "64", "-b", "1", str(src), str(packed)], check=True)
+    K, frame_bytes, raw_bytes, frames = _read_container(packed.read_bytes())
+    assert (K, frame_bytes, raw_bytes) == (32, 64 << 10, len(raw))
+    for i, fr in enumerate(frames):  # every frame is the reference's CompressMulti<32>(chunk)
+        assert fr == oracle.compress(32, raw[i * frame_bytes:(i + 1) * frame_bytes]), i
+    subprocess.run([tool, "d", "-b", "1", str(packed), str(back)], check=True)
+    assert back.read_bytes() == raw
+    subprocess.run([tool, "t", str(packed)], check=True)
+    # an empty file and a damaged container
+    (tmp_path / "empty").write_bytes(b"")
+    subprocess.run([tool, "c", str(tmp_path / "empty"), str(tmp_path / "empty.hfz")], check=True)
+    subprocess.run([tool, "d", str(tmp_path / "empty.hfz"), str(tmp_path / "empty.out")], check=True)
+    assert (tmp_path / "empty.out").read_bytes() == b""
+    bad = bytearray(packed.read_bytes())
+    bad[32 + 4 * len(frames) + 9] ^= 0xff  # inside the first frame's code section
+    (tmp_path / "bad.hfz").write_bytes(bytes(bad))
+    r = subprocess.run([tool, "t", str(tmp_path / "bad.hfz")], capture_output=True)
+    assert r.returncode != 0
+    r = subprocess.run([tool, "t", str(packed)[:-4] + ".bin"], capture_output=True)  # not a container
+    assert r.returncode != 0
