@@ -135,6 +135,10 @@ def test_generator_matches_oracle(torch_cuda):
     (1, 5000, 1000, True),
     (64, 1000, 7, False),       # fewer bytes than streams in every frame
     (8, 0, 4096, False),        # empty batch -> one empty frame
+    (1, 6 << 20, 6 << 20, False),          # one stream, one large frame
+    (2, (5 << 20) + 3, 3 << 20, False),    # 32-bit per-stream counters, ragged second frame
+    (64, 9 << 20, 5 << 20, False),         # slices beyond 65535 bytes: separate histogram and sizes passes
+    (48, 3 << 20, 1 << 20, True),
 ])
 def test_batch_frames_equal_oracle(torch_cuda, K, total, frame_bytes, strided):
     torch = torch_cuda
