@@ -213,6 +213,19 @@ def histogram_dev(raw):
     return total
 
 
+def scale_histogram(hist):
+    """256 counts of any width -> uint32 counts for the code builder: while the
+    largest count needs more than 32 bits all counts are halved (floor), but a
+    symbol that occurs at all keeps a count of at least 1, so it keeps a code."""
+    h = np.asarray(hist, dtype=np.uint64).reshape(256)
+    shift = 0
+    while (int(h.max(initial=0)) >> shift) > 0xffffffff:
+        shift += 1
+    if shift:
+        h = np.where(h > 0, np.maximum(h >> np.uint64(shift), np.uint64(1)), np.uint64(0))
+    return h.astype(np.uint32)
+
+
 def build_code_table(hist):
     """MakeCanonicalCoding (codec/huffman.cpp:339-437); host only."""
     h = np.ascontiguousarray(hist, dtype=np.uint32)
@@ -322,13 +335,7 @@ class BatchCodec:
         """hist: 256 counts (any integer width).  Counts beyond 32 bits are scaled
         down, keeping every symbol that occurs at all."""
         torch = self.torch
-        h = np.asarray(hist, dtype=np.uint64)
-        shift = 0
-        while int(h.max(initial=0)) >> shift > 0xffffffff:
-            shift += 1
-        if shift:
-            h = np.where(h > 0, np.maximum(h >> np.uint64(shift), 1), 0)
-        fc = frame_code(h.astype(np.uint32))
+        fc = frame_code(scale_histogram(hist))
         host = torch.frombuffer(bytearray(bytes(fc)), dtype=torch.uint8)
         return host.to(self.device)
 

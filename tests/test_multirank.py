@@ -54,6 +54,56 @@ def _worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+def _shared_code_worker(rank, world, port, tmpdir):
+    # config "one code for the whole job": every rank counts its own shard, the
+    # 256 counters are summed over ranks (the job's only exchange), every rank
+    # builds the code from the sum and codes its frames with it
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import oracle
+    hfz = importlib.import_module("huffman-avx512_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, frame_bytes, total = 16, 5000, 5000 * 6 + 77
+    cdf = hfz.distributions.geometric_cdf() if rank == 0 else hfz.distributions.enwik_like_cdf()
+    raw = oracle.generate(cdf, 100 + rank, total).tobytes()  # every rank its own data
+    h = torch.from_numpy(oracle.histogram(raw).astype(np.int64))
+    dist.all_reduce(h)
+    h32 = hfz.scale_histogram(h.numpy())
+    record = bytes(hfz.frame_code(h32))            # host builder of the library
+    coding = oracle.make_coding(h32)               # the oracle's builder
+    frames = [oracle.compress_with_coding(K, coding, raw[i:i + frame_bytes])
+              for i in range(0, total, frame_bytes)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (record, bytes(h32.tobytes()), frames, raw))
+    if rank == 0:
+        assert all(g[0] == gathered[0][0] and g[1] == gathered[0][1] for g in gathered)
+        fc = hfz.frame_code(h32)
+        code_section = bytes(fc.hdr)[:fc.hdr_len]
+        for _, _, frs, data in gathered:
+            for i, fr in enumerate(frs):
+                assert fr[4:4 + len(code_section)] == code_section  # same code in every frame
+                assert oracle.decompress(K, fr) == data[i * frame_bytes:(i + 1) * frame_bytes]
+        # counts beyond 32 bits keep every occurring symbol
+        big = np.zeros(256, dtype=np.uint64)
+        big[0], big[1], big[2] = 1 << 40, 3, 0
+        s = hfz.scale_histogram(big)
+        assert s[0] == 1 << 31 and s[1] == 1 and s[2] == 0
+        open(os.path.join(tmpdir, "ok2"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shared_code(tmp_path):
+    import torch.multiprocessing as mp
+    port = 30100 + (os.getpid() % 500)
+    mp.spawn(_shared_code_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok2").exists()
+
+
 def test_two_ranks_shard_frames(tmp_path):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 500)
