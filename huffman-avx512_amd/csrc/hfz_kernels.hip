@@ -1,7 +1,8 @@
-// gfx950 kernels of the K-stream Huffman codec: byte histogram, per-stream
-// coded size, frame placement, encode, decode-table build + decode, and the
-// synthetic data source.  One wavefront (64 lanes) owns one frame and one lane
-// owns one stream of it.
+// gfx950 kernels of the K-stream Huffman codec: per-stream byte counts (and the
+// plain histogram), canonical code construction, per-stream coded sizes, frame
+// placement, encode, decode-table build + decode, and the synthetic data source.
+// In the encoder and the decoder one wavefront (64 lanes) owns one frame and one
+// lane one stream of it (two frames per wave for K <= 32 on large batches).
 #include <hip/hip_runtime.h>
 
 #include "hfz_internal.h"
@@ -26,8 +27,9 @@ __device__ __forceinline__ Slice slice_of(uint32_t n, uint32_t K, uint32_t k) {
   return s;
 }
 
-// Diagnostic build only (-DHFZ_STAMP): per-phase cycle sums of the decode
-// kernel, read back with hfz_debug_stamps().  Never compiled into libhfz.so.
+// Diagnostic build only (-DHFZ_STAMP): per-phase cycle sums of the decode and
+// encode kernels and of the code builder, read back with hfz_debug_stamps().
+// Never compiled into libhfz.so.
 #ifdef HFZ_STAMP
 __device__ unsigned long long g_stamps[32];
 #define STAMP_DECL() unsigned long long st_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[8] = {}
@@ -1183,8 +1185,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
 //
 // Every lane moves its own stream between global memory and LDS in whole,
 // aligned blocks: 64-byte input blocks (four 16-byte loads) into a two-block
-// ring (plus an 8-byte mirror of its first bytes so that a 12-byte read never
-// wraps), 32-byte output blocks from a two-block ring.  Streams of one
+// ring, 32-byte output blocks from a two-block ring.  Streams of one
 // frame lie n/K bytes apart, so neighbouring lanes never share a cache line
 // anyway; what matters is that each line is moved in few, aligned pieces.
 //
@@ -1202,6 +1203,7 @@ constexpr uint32_t kDecOutDw = 16;   // output ring per lane: 64 bytes
 // Both rings are stored transposed, dword d of lane l at [d * 64 + l]: whatever
 // ring positions the lanes are at, an access puts lane l on bank l % 32, so the
 // rings never cause bank conflicts and need no padding.
+//
 // The decoder exists in two builds.  With kDecTabBits = 11 the lookup table is
 // indexed by the next 11 bits, not 12: it is half the size
 // (8 KiB), which is what bounds the number of resident waves per CU.  Codes of
