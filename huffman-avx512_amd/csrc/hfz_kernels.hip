@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
 // per-stream counts count_kernel left in memory (same layout as its LDS array).
 // Lane l walks the rows of parity l / 32 and owns counter word l % 32.
 // given != null: no code is built; the sizes are those under given[f * given_step].
-__global__ __launch_bounds__(64) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ counts,
                                                         FrameCode* __restrict__ code,
                                                         const FrameCode* __restrict__ given,

@@ -31,8 +31,8 @@ def child(lib, cfgs):
         torch.cuda.synchronize()
         kt = hfz.timing_read(); hfz.timing_enable(False)
         ok = bool(torch.equal(out, raw))
-        print("%-28s %-18s hist %.4f sizes %.4f enc %.4f dec %.4f  sum %.4f ms  ok=%s" % (
-            os.path.basename(lib), cfg, kt["hist_ms"], kt["sizes_ms"], kt["encode_ms"], kt["decode_ms"],
+        print("%-28s %-18s hist %.4f code %.4f sizes %.4f enc %.4f dec %.4f  sum %.4f ms  ok=%s" % (
+            os.path.basename(lib), cfg, kt["hist_ms"], kt["table_ms"], kt["sizes_ms"], kt["encode_ms"], kt["decode_ms"],
             sum(kt[k + "_ms"] for k in ("hist", "table", "sizes", "place", "encode", "decode")), ok),
             flush=True)
         del codec, raw, out, b
