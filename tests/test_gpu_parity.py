@@ -532,3 +532,43 @@ def test_command_line_tool_round_trip(torch_cuda, tmp_path):
     assert r.returncode != 0
     r = subprocess.run([tool, "t", str(packed)[:-4] + ".bin"], capture_output=True)  # not a container
     assert r.returncode != 0
+
+
+# ---- randomized sweep ----------------------------------------------------------
+
+def test_random_batches_equal_oracle(torch_cuda):
+    # fixed-seed sweep over stream counts, frame sizes (down to a few bytes), batch
+    # shapes, layouts and sources, under both decoder tables and both lane mappings
+    torch = torch_cuda
+    rng = np.random.default_rng(20240611)
+    sources = [hfz.distributions.geometric_cdf(), hfz.distributions.enwik_like_cdf(),
+               hfz.distributions.cdf_from_weights([1] * 256),               # uniform: 8-bit codes
+               hfz.distributions.cdf_from_weights([1000, 1] + [0] * 254),   # two symbols
+               hfz.distributions.cdf_from_weights([1 << (40 - i) for i in range(40)] + [0] * 216)]
+    try:
+        for case in range(48):
+            K = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 33, 48, 63, 64]))
+            frame_bytes = int(rng.choice([1, 17, 100, 1000, 4096, 30000, 65536, 150000]))
+            n_frames = int(rng.integers(1, 9))
+            total = max(0, frame_bytes * n_frames - int(rng.integers(0, frame_bytes)))
+            src = sources[int(rng.integers(0, len(sources)))]
+            strided = bool(rng.integers(0, 2))
+            hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12])))
+            hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
+            raw = hfz.generate(src, 1000 + case, total) if total else torch.empty(
+                0, dtype=torch.uint8, device="cuda")
+            host = raw.cpu().numpy().tobytes()
+            codec = hfz.BatchCodec(K, total, frame_bytes, strided=strided)
+            batch = codec.compress(raw)
+            out = codec.decompress(batch)
+            torch.cuda.synchronize()
+            tag = (case, K, frame_bytes, total, strided)
+            assert int(codec.status.abs().sum().item()) == 0, tag
+            assert int(codec.dstatus.abs().sum().item()) == 0, tag
+            assert out.cpu().numpy().tobytes() == host, tag
+            for i in range(codec.n_frames):
+                assert batch.frame_bytes_host(i) == oracle.compress(
+                    K, host[i * frame_bytes:(i + 1) * frame_bytes]), tag + (i,)
+    finally:
+        hfz.set_decoder_table_bits(0)
+        hfz.set_frames_per_wave(0)
