@@ -38,7 +38,7 @@ EXPORTS = (
     "hfz_histogram_batch_dev", "hfz_generate_dev", "hfz_timing_enable", "hfz_timing_read",
     "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
     "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
-    "hfz_count_batch_dev", "hfz_compress_batch_counted_dev",
+    "hfz_count_batch_dev", "hfz_compress_batch_counted_dev", "hfz_set_encoder_block",
 )
 
 
@@ -134,6 +134,8 @@ def lib():
         L.hfz_build_codes_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_timing_enable.restype = ci
         L.hfz_timing_enable.argtypes = [ci]
+        L.hfz_set_encoder_block.restype = ci
+        L.hfz_set_encoder_block.argtypes = [ci]
         L.hfz_set_frames_per_wave.restype = ci
         L.hfz_set_frames_per_wave.argtypes = [ci]
         L.hfz_set_decoder_table_bits.restype = ci
@@ -407,6 +409,11 @@ def set_decoder_table_bits(bits=0):
 def set_frames_per_wave(n=0):
     """0 = automatic, 1 = one frame per wave, 2 = two (K <= 32)."""
     _check(lib().hfz_set_frames_per_wave(int(n)), "hfz_set_frames_per_wave")
+
+
+def set_encoder_block(nbytes=0):
+    """0 = automatic, 32 or 64 = bytes per block the encoder stores."""
+    _check(lib().hfz_set_encoder_block(int(nbytes)), "hfz_set_encoder_block")
 
 
 def timing_enable(on=True):

@@ -448,6 +448,12 @@ int hfz_set_frames_per_wave(int n) {
   return HFZ_OK;
 }
 
+int hfz_set_encoder_block(int bytes) {
+  if (bytes != 0 && bytes != 32 && bytes != 64) return HFZ_E_ARG;
+  g_encoder_block = bytes;
+  return HFZ_OK;
+}
+
 int hfz_timing_enable(int on) {
   g_timing.on = on != 0;
   g_timing.enc_calls = g_timing.dec_calls = 0;

@@ -56,6 +56,8 @@ inline WorkspaceLayout workspace_layout(size_t n) {
 extern int g_decoder_table_bits;
 // 0 = choose by frame count, 1 / 2 = forced (hfz_set_frames_per_wave).
 extern int g_frames_per_wave;
+// 0 = choose by frame count, 32 / 64 = forced (hfz_set_encoder_block).
+extern int g_encoder_block;
 
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);

@@ -958,7 +958,7 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t* __restric
 // LDS ring, from which whole aligned 32-byte blocks are stored.  The LDS table
 // holds (code << 20) | len per symbol, so two codes are merged with 32-bit
 // operations before one 64-bit shift places them in the accumulator.
-constexpr uint32_t kEncBlk = 32;
+constexpr uint32_t kEncBlk = 32;     // bytes per input block
 constexpr uint32_t kEncRingDw = 32;  // output ring per lane: 128 bytes
 constexpr uint32_t kEncGroup = 4;    // input blocks loaded at once per lane
 
@@ -966,13 +966,18 @@ constexpr uint32_t kEncGroup = 4;    // input blocks loaded at once per lane
 // offset p (a multiple of 4) of lane l lives at ring row ~(p >> 2) & 31, LDS
 // dword [row * 64 + l].  Lane l is always on bank l % 32 (no conflicts, no
 // padding), the ring address of the dword being filled only ever grows (by one
-// row per finished dword), and an aligned 32-byte output block is one aligned
-// group of eight rows in reverse order.
+// row per finished dword), and an aligned 32- or 64-byte output block is one
+// aligned group of eight or sixteen rows in reverse order.
 //
 // kF = frames per wave.  With K <= 32 a frame would leave half the lanes idle,
 // so lanes 0..31 take frame 2b and lanes 32..63 frame 2b+1 of workgroup b (each
 // half with its own code table); everything past the prologue is per lane anyway.
-template <uint32_t kF>
+//
+// kEncOutBlk = bytes per stored output block: 64 on large batches, where fewer,
+// larger pieces of a line reach memory (18 % faster at 1 GiB and beyond), 32
+// when every SIMD has a single wave and the shorter wait for the ring reads
+// matters more (9 % faster at 1024 frames).
+template <uint32_t kF, uint32_t kEncOutBlk>
 __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     uint64_t n_frames, const FrameCode* __restrict__ code, uint32_t code_step,
@@ -980,6 +985,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint8_t* __restrict__ comp, uint64_t cap) {
   static_assert(kF == 1 || kF == 2, "one or two frames per wave");
+  static_assert(kEncOutBlk == 32 || kEncOutBlk == 64, "the ring holds four or two blocks");
   __shared__ uint32_t enc_all[kF * 256];
   __shared__ uint32_t oring[64 * kEncRingDw];
   const uint32_t lane = threadIdx.x;
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
   // the global address space)
   const uint8_t* const frame_in = raw + f * frame_bytes;
   const uint8_t* const ibase = frame_in - ((uintptr_t)frame_in & 31);
-  uint8_t* const obase = out - ((uintptr_t)out & 31);
+  uint8_t* const obase = out - ((uintptr_t)out & (kEncOutBlk - 1));
   const Slice s = slice_of(n, K, k);
   const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
   const uint32_t r_hi = area + stream_end[f * 64 + k];
@@ -1038,8 +1044,8 @@ __global__ __launch_bounds__(64) void encode_kernel(
   const uint32_t wp0 = (r_hi + 3) & ~3u;
   const uint32_t ua0 = ((~((wp0 - 4) >> 2)) & (kEncRingDw - 1)) << 8;
   uint32_t ua = ua0;
-  uint32_t nf = (r_hi - 1) & ~(kEncBlk - 1);  // next block to store (descending)
-  const uint32_t nf_last = r_lo & ~(kEncBlk - 1);
+  uint32_t nf = (r_hi - 1) & ~(kEncOutBlk - 1);  // next block to store (descending)
+  const uint32_t nf_last = r_lo & ~(kEncOutBlk - 1);
   bool nf_live = true;
   constexpr uint32_t kRowMask = (kEncRingDw - 1) << 8;
 
@@ -1070,19 +1076,22 @@ __global__ __launch_bounds__(64) void encode_kernel(
     acc <<= full_;                                                            \
     nb = nbs_ & 31;                                                           \
   } while (0)
-  // stores the ring block holding output offsets [blk, blk+32); only bytes of
+  // stores the ring block holding output offsets [blk, blk+kEncOutBlk); only bytes of
   // this stream's region [r_lo, r_hi) are written
 #define HFZ_STORE_BLOCK(blk)                                                  \
   do {                                                                        \
-    const uint8_t* g_ = ocol + (((~((blk) >> 2)) & (kEncRingDw - 8)) << 8);   \
-    uint32_t sb_[8];                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                          \
-      sb_[q_] = *(const uint32_t*)(g_ + 256 * (7 - q_));                      \
-    if ((blk) >= r_lo && (blk) + kEncBlk <= r_hi) {                           \
-      *(uint4*)(obase + (blk)) = make_uint4(sb_[0], sb_[1], sb_[2], sb_[3]);  \
-      *(uint4*)(obase + (blk) + 16) = make_uint4(sb_[4], sb_[5], sb_[6], sb_[7]); \
+    constexpr int kDw_ = kEncOutBlk / 4;                                      \
+    const uint8_t* g_ = ocol + (((~((blk) >> 2)) & (kEncRingDw - kDw_)) << 8); \
+    uint32_t sb_[kDw_];                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < kDw_; ++q_)                       \
+      sb_[q_] = *(const uint32_t*)(g_ + 256 * (kDw_ - 1 - q_));               \
+    if ((blk) >= r_lo && (blk) + kEncOutBlk <= r_hi) {                        \
+      _Pragma("unroll") for (int q_ = 0; q_ < kDw_ / 4; ++q_)                 \
+        *(uint4*)(obase + (blk) + 16 * q_) =                                  \
+            make_uint4(sb_[4 * q_], sb_[4 * q_ + 1], sb_[4 * q_ + 2], sb_[4 * q_ + 3]); \
     } else {                                                                  \
-      store_block_clipped(obase, (blk), sb_, r_lo, r_hi);                     \
+      _Pragma("unroll") for (int q_ = 0; q_ < kDw_ / 8; ++q_)                 \
+        store_block_clipped(obase, (blk) + 32 * q_, sb_ + 8 * q_, r_lo, r_hi); \
     }                                                                         \
   } while (0)
 
@@ -1141,7 +1150,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
         if (nf_live && wp <= nf) {
           HFZ_STORE_BLOCK(nf);
           if (nf == nf_last) nf_live = false;
-          nf -= kEncBlk;
+          nf -= kEncOutBlk;
         }
       }
     }
@@ -1165,7 +1174,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
   while (nf_live) {
     HFZ_STORE_BLOCK(nf);
     if (nf == nf_last) nf_live = false;
-    nf -= kEncBlk;
+    nf -= kEncOutBlk;
   }
 #undef HFZ_PAIR
 #undef HFZ_ONE
@@ -1745,6 +1754,7 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 int g_decoder_table_bits = 0;
 int g_frames_per_wave = 0;
+int g_encoder_block = 0;
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -1851,16 +1861,19 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
                   const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  if (pair_frames(K, n_frames))
-    hipLaunchKernelGGL(encode_kernel<2>, dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames, d_code,
-                       shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size, d_comp,
-                       comp_cap);
-  else
-    hipLaunchKernelGGL(encode_kernel<1>, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                       (uint32_t)K, d_raw, total, frame_bytes, n_frames, d_code,
-                       shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size, d_comp,
-                       comp_cap);
+  const bool pair = pair_frames(K, n_frames);
+  const bool wide = g_encoder_block ? g_encoder_block == 64
+                                    : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
+  const dim3 grid((uint32_t)(pair ? (n_frames + 1) / 2 : n_frames));
+#define HFZ_LAUNCH_ENCODE(F, B)                                                                  \
+  hipLaunchKernelGGL((encode_kernel<F, B>), grid, dim3(64), 0, as_stream(stream), (uint32_t)K,  \
+                     d_raw, total, frame_bytes, n_frames, d_code, shared_code ? 0u : 1u,         \
+                     d_stream_end, d_comp_off, d_comp_size, d_comp, comp_cap)
+  if (pair && wide) HFZ_LAUNCH_ENCODE(2, 64);
+  else if (pair) HFZ_LAUNCH_ENCODE(2, 32);
+  else if (wide) HFZ_LAUNCH_ENCODE(1, 64);
+  else HFZ_LAUNCH_ENCODE(1, 32);
+#undef HFZ_LAUNCH_ENCODE
   return hipGetLastError();
 }
 

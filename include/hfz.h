@@ -247,6 +247,14 @@ int hfz_set_decoder_table_bits(int bits);
 int hfz_set_frames_per_wave(int n);
 
 /*
+ * The encoder writes its streams in aligned blocks of 32 or 64 bytes; bytes = 0
+ * (default) takes 64 once the batch has more frames than SIMDs, 32 below.
+ * 32 / 64 force one, for tests and tuning.  Output is identical.  Process-wide;
+ * no counterpart in the reference.
+ */
+int hfz_set_encoder_block(int bytes);
+
+/*
  * Deterministic integer-only synthetic source, filled on the device:
  * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
  * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).

@@ -82,6 +82,20 @@ def test_both_decoder_table_builds(torch_cuda, bits):
         hfz.set_decoder_table_bits(0)
 
 
+def test_encoder_block_sizes(torch_cuda):
+    # the encoder picks 32- or 64-byte output blocks by frame count; force each one
+    # over every reference case
+    try:
+        for nbytes in (32, 64):
+            hfz.set_encoder_block(nbytes)
+            for name in CASE_FILES:
+                raw = load_input(name)
+                for K in KS:
+                    assert hfz.compress(K, raw) == oracle.compress(K, raw), (nbytes, name, K)
+    finally:
+        hfz.set_encoder_block(0)
+
+
 def test_other_stream_counts(torch_cuda):
     # the AVX-512 paths of the reference also run K = 24, 40, 48
     raw = load_input("long_random.bin")
@@ -555,6 +569,7 @@ def test_random_batches_equal_oracle(torch_cuda):
             strided = bool(rng.integers(0, 2))
             hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12])))
             hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
+            hfz.set_encoder_block(int(rng.choice([0, 32, 64])))
             raw = hfz.generate(src, 1000 + case, total) if total else torch.empty(
                 0, dtype=torch.uint8, device="cuda")
             host = raw.cpu().numpy().tobytes()
@@ -572,3 +587,4 @@ def test_random_batches_equal_oracle(torch_cuda):
     finally:
         hfz.set_decoder_table_bits(0)
         hfz.set_frames_per_wave(0)
+        hfz.set_encoder_block(0)
