@@ -416,8 +416,9 @@ def set_encoder_block(nbytes=0):
     _check(lib().hfz_set_encoder_block(int(nbytes)), "hfz_set_encoder_block")
 
 
-def timing_enable(on=True):
-    _check(lib().hfz_timing_enable(1 if on else 0), "hfz_timing_enable")
+def timing_enable(every=1):
+    """Record kernel times on every `every`-th batch call (True = 1, False/0 = off)."""
+    _check(lib().hfz_timing_enable(int(every)), "hfz_timing_enable")
 
 
 def timing_read():

@@ -26,19 +26,23 @@ int hip_fail(hipError_t e) {
     if (e__ != hipSuccess) return hip_fail(e__); \
   } while (0)
 
-// Per-thread event sets for hfz_timing_*: every batch call made while timing
-// is on takes a fresh set, records an event before and after each of its
-// kernels, and hfz_timing_read averages over all sets taken since the last
-// read.
+// Per-thread event sets for hfz_timing_*: while timing is on, every `every`-th
+// batch call of a kind (the first included) takes a fresh set and records an
+// event before and after each of its kernels; hfz_timing_read averages over all
+// sets taken since the last read.  Events between kernels keep one kernel's
+// tail from overlapping the next one's start, which costs a few percent of a
+// short batch: sampling keeps the measurement and most of the overlap.
 constexpr int kEncEvents = 6, kDecEvents = 2, kMaxTimedCalls = 512;
 struct Timing {
-  bool on = false;
-  std::vector<hipEvent_t> enc, dec;  // kEncEvents / kDecEvents per call
-  size_t enc_calls = 0, dec_calls = 0;
+  int every = 0;                     // 0 = off
+  std::vector<hipEvent_t> enc, dec;  // kEncEvents / kDecEvents per timed call
+  size_t enc_calls = 0, dec_calls = 0;  // timed calls
+  size_t enc_seen = 0, dec_seen = 0;    // all calls while on
   hipEvent_t* cur = nullptr;
-  hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, int per_call) {
+  hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, size_t& seen, int per_call) {
     cur = nullptr;
-    if (!on || calls >= (size_t)kMaxTimedCalls) return hipSuccess;
+    if (every <= 0) return hipSuccess;
+    if (seen++ % (size_t)every != 0 || calls >= (size_t)kMaxTimedCalls) return hipSuccess;
     while (v.size() < (calls + 1) * per_call) {
       hipEvent_t e;
       hipError_t r = hipEventCreate(&e);
@@ -274,7 +278,7 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
   const bool shared = d_shared != nullptr;
   const FrameCode* enc_code = shared ? d_shared : d_code;
 
-  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents));
   HFZ_HIP(mark(0, st));
   if (count_kernel_fits(K, frame_bytes)) {
     // one pass over the input for the per-stream counts (hist_ms), then code and
@@ -315,7 +319,7 @@ int decompress_batch(int K, const void* d_comp, size_t comp_bytes, const uint64_
       (raw_cap && !d_raw))
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
-  HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, kDecEvents));
+  HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, g_timing.dec_seen, kDecEvents));
   HFZ_HIP(mark(0, (hipStream_t)stream));
   HFZ_HIP(launch_decode(K, (const uint8_t*)d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames,
                         shared, (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
@@ -375,7 +379,7 @@ int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_
   const FrameCode* code = (const FrameCode*)d_code;
   const uint8_t* raw = (const uint8_t*)d_raw;
   hipStream_t st = (hipStream_t)stream;
-  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, kEncEvents));
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents));
   HFZ_HIP(mark(0, st));
   HFZ_HIP(mark(1, st));  // the input pass was hfz_count_batch_dev
   if (count_kernel_fits(K, frame_bytes)) {
@@ -454,9 +458,11 @@ int hfz_set_encoder_block(int bytes) {
   return HFZ_OK;
 }
 
-int hfz_timing_enable(int on) {
-  g_timing.on = on != 0;
+int hfz_timing_enable(int every) {
+  if (every < 0) return HFZ_E_ARG;
+  g_timing.every = every;
   g_timing.enc_calls = g_timing.dec_calls = 0;
+  g_timing.enc_seen = g_timing.dec_seen = 0;
   g_timing.cur = nullptr;
   return HFZ_OK;
 }
@@ -488,6 +494,7 @@ int hfz_timing_read(hfz_batch_timing* out) {
   out->compress_calls = (int32_t)g_timing.enc_calls;
   out->decompress_calls = (int32_t)g_timing.dec_calls;
   g_timing.enc_calls = g_timing.dec_calls = 0;
+  g_timing.enc_seen = g_timing.dec_seen = 0;
   return HFZ_OK;
 }
 

@@ -209,10 +209,14 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
 /*
  * Optional per-kernel timing of the batch entry points, taken with HIP events
  * on the caller's stream (used by the benchmark to price each kernel against
- * its roofline).  hfz_timing_enable(1) makes the following batch calls of this
- * thread record events (at most 512 calls of each kind between reads);
- * hfz_timing_read waits for them, returns the mean milliseconds per call of
- * each kernel over the calls recorded since the previous read, and starts a
+ * its roofline).  hfz_timing_enable(n), n >= 1, makes every n-th of the following
+ * batch calls of each kind on this thread (the first included) record an event
+ * before and after each of its kernels (at most 512 recorded calls of each kind
+ * between reads); 0 turns it off.  Events between kernels stop one kernel's
+ * tail from overlapping the next kernel's start, about 5 % of a 256 MiB batch,
+ * so a benchmark samples (n = 4) rather than timing every call.
+ * hfz_timing_read waits for the events, returns the mean milliseconds per call
+ * of each kernel over the calls recorded since the previous read, and starts a
  * new window.  Has no counterpart in the reference.
  */
 typedef struct hfz_batch_timing {
@@ -225,7 +229,7 @@ typedef struct hfz_batch_timing {
   int32_t compress_calls;   /* calls averaged into the first five fields */
   int32_t decompress_calls; /* calls averaged into decode_ms */
 } hfz_batch_timing;
-int hfz_timing_enable(int on);
+int hfz_timing_enable(int every);
 int hfz_timing_read(hfz_batch_timing* out);
 
 /*
