@@ -337,25 +337,15 @@ __device__ void introsort_loop(const SortArrays& a, int n, int* stk, uint32_t* l
   }
 }
 
-// Element i of a 256-entry array kept in four registers across the wave; i is
-// wave-uniform.
-__device__ __forceinline__ uint32_t lane_get(const uint32_t (&a)[4], int i) {
-  const int l = i & 63;
-  switch (i >> 6) {
-    case 0: return __builtin_amdgcn_readlane(a[0], l);
-    case 1: return __builtin_amdgcn_readlane(a[1], l);
-    case 2: return __builtin_amdgcn_readlane(a[2], l);
-    default: return __builtin_amdgcn_readlane(a[3], l);
-  }
+// Register r (wave-uniform) of four; used where r changes rarely.
+__device__ __forceinline__ uint32_t pick4(const uint32_t (&a)[4], int r) {
+  return r <= 0 ? a[0] : r == 1 ? a[1] : r == 2 ? a[2] : a[3];
 }
-__device__ __forceinline__ void lane_set(uint32_t (&a)[4], int i, uint32_t v, uint32_t lane) {
-  const bool mine = lane == (uint32_t)(i & 63);
-  switch (i >> 6) {
-    case 0: a[0] = mine ? v : a[0]; break;
-    case 1: a[1] = mine ? v : a[1]; break;
-    case 2: a[2] = mine ? v : a[2]; break;
-    default: a[3] = mine ? v : a[3]; break;
-  }
+__device__ __forceinline__ void put4(uint32_t (&a)[4], int r, uint32_t v) {
+  a[0] = r == 0 ? v : a[0];
+  a[1] = r == 1 ? v : a[1];
+  a[2] = r == 2 ? v : a[2];
+  a[3] = r == 3 ? v : a[3];
 }
 
 // Builds the code of one frame from its histogram hist[256] (global or LDS)
@@ -398,13 +388,19 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   if (n > 16) introsort_loop(arr, n, stk, tcount, key2, lane);  // both lists are free until later
   wave_sync();
   STAMP(1);  // partition loop
-  // stable order by descending count = what the final insertion sort leaves
+  // Stable order by descending count = what the final insertion sort leaves.
+  // The partition loop leaves runs of at most 16 elements that are already in
+  // order among each other, so an element moves fewer than 16 places and only
+  // its 15 neighbours on either side decide its rank.
   for (int i = (int)lane; i < n; i += 64) {
     const uint32_t k = key[i];
-    int rank = 0;
-    for (int m = 0; m < n; ++m) {
-      const uint32_t km = key[m];
-      rank += (km > k) || (km == k && m < i);
+    int rank = i > 15 ? i - 15 : 0;
+#pragma unroll
+    for (int d = -15; d <= 15; ++d) {
+      const int m = i + d;
+      const bool in = m >= 0 && m < n;
+      const uint32_t km = key[in ? m : i];
+      rank += in && (km > k || (km == k && d < 0));
     }
     sym2[rank] = sym[i];
     key2[rank] = k;
@@ -414,17 +410,22 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   STAMP(2);  // rank sort
   // Two-queue Huffman merge (:364-416); records each leaf's and node's parent.
   // Inherently serial, so it runs as wave-uniform scalar code with both queues in
-  // registers (element i = lane i & 63 of register i >> 6, read and written
-  // with v_readlane / v_writelane): a step costs a few scalar instructions
-  // instead of two dependent LDS round trips.
+  // registers: element i is lane i & 63 of register i >> 6.  Each queue is walked
+  // one way, so the register that holds its head changes every 64 elements only;
+  // a copy of that register is kept at hand and a step needs one v_readlane per
+  // element taken and one lane-select per node made, no LDS round trip.
+  //   leaves: kq[], head ns going down, kcur = kq[ns >> 6]
+  //   nodes:  made at ts, taken at nt, both going up; tw collects block ts >> 6
+  //           and moves to tq[] when it is full; tr = block nt >> 6 once full
   uint32_t kq[4], tq[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) kq[r] = key2[64 * r + lane];
   int ts = 0;
   {
     int ns = n - 1, nt = 0;
-    uint32_t lk = ns >= 0 ? lane_get(kq, ns) : 0;  // head of the leaf queue
-    uint32_t nk = 0;                               // head of the node queue (valid if nt < ts)
+    uint32_t kcur = pick4(kq, ns >> 6), tw = 0, tr = 0;
+    uint32_t lk = __builtin_amdgcn_readlane(kcur, ns & 63);  // head of the leaf queue
+    uint32_t nk = 0;                                         // head of the node queue (valid if nt < ts)
     while ((ts - nt) + (ns + 1) > 1) {
       uint32_t sum = 0;
 #pragma unroll
@@ -432,21 +433,29 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
         const bool leaf = ns >= 0 && (nt == ts || lk <= nk);  // a leaf wins a tie (:375)
         if (leaf) {
           sum += lk;
-          if (lane == 0) lparent[ns] = (uint16_t)ts;
+          lparent[ns] = (uint16_t)ts;  // the same store from every lane
           --ns;
-          if (ns >= 0) lk = lane_get(kq, ns);
+          if ((ns & 63) == 63 && ns >= 0) kcur = pick4(kq, ns >> 6);
+          lk = __builtin_amdgcn_readlane(kcur, ns & 63);  // unused once ns < 0
         } else {
           sum += nk;
-          if (lane == 0) parent[0][nt] = (uint16_t)ts;
+          parent[0][nt] = (uint16_t)ts;
           ++nt;
-          if (nt < ts) nk = lane_get(tq, nt);
+          if ((nt & 63) == 0) tr = pick4(tq, nt >> 6);  // stale if that block is still tw: not read then
+          nk = __builtin_amdgcn_readlane((nt >> 6) == (ts >> 6) ? tw : tr, nt & 63);  // unused if nt == ts
         }
       }
-      lane_set(tq, ts, sum, lane);
+      tw = lane == (uint32_t)(ts & 63) ? sum : tw;
       if (nt == ts) nk = sum;  // the queue was empty: the new node is its head
       ++ts;
+      if ((ts & 63) == 0) {  // block full (at most three times)
+        const int b = (ts >> 6) - 1;
+        put4(tq, b, tw);
+        if ((nt >> 6) == b) tr = tw;
+        tw = 0;
+      }
     }
-    if (lane == 0 && ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
+    if (ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);  // root points to itself
   }
   wave_sync();
   STAMP(3);  // merge
@@ -488,11 +497,24 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
     uint32_t kraft = 0;
 #pragma unroll
     for (int L = 0; L <= kMaxCodeLen; ++L) kraft += lc[L] << (kMaxCodeLen - L);
+    // One round of the fix-up loop takes a code of the longest length j < 12 in
+    // use, lengthens it, and drops the Kraft sum by one.  While length 11 is in
+    // use every round does the same thing (lc[11] - 1, lc[12] - 1 + 2), so those
+    // rounds are applied together; any other j is a round of its own and leaves
+    // two codes at j + 1.
     while (kraft > (1u << kMaxCodeLen)) {
+      const uint32_t excess = kraft - (1u << kMaxCodeLen);
+      if (lc[kMaxCodeLen - 1] > 0) {
+        const uint32_t t = lc[kMaxCodeLen - 1] < excess ? lc[kMaxCodeLen - 1] : excess;
+        lc[kMaxCodeLen - 1] -= t;
+        lc[kMaxCodeLen] += t;
+        kraft -= t;
+        continue;
+      }
       --lc[kMaxCodeLen];
       bool done = false;
 #pragma unroll
-      for (int j = kMaxCodeLen - 1; j >= 0; --j) {
+      for (int j = kMaxCodeLen - 2; j >= 0; --j) {
         if (!done && lc[j] > 0) {
           --lc[j];
           lc[j + 1] += 2;
@@ -540,6 +562,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   for (int i = (int)lane; i < n; i += 64) hb[4 + nlen + i] = sym2[i];
   wave_sync();
 
+  STAMP(6);  // canonical codes, header
   FrameCode& out = *out_p;
   uint32_t* enc_out = (uint32_t*)out.enc;
   const uint32_t* encs32 = (const uint32_t*)encs;
@@ -547,7 +570,7 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
   uint32_t* hdr_out = (uint32_t*)out.hdr;
   for (uint32_t i = lane; i < 69; i += 64) hdr_out[i] = hdrw[i];
   if (lane == 0) out.hdr_len = 4 + nlen + (uint32_t)n;
-  STAMP(6);  // canonical codes, header, write-out
+  STAMP(7);  // write-out
   STAMP_FLUSH(16);
   return encs;
 }

@@ -10,10 +10,12 @@ hfz.LIB_PATH = os.path.join(ROOT, "tools", "libhfz_stamp.so")
 L = hfz.lib()
 geometric_cdf = hfz.distributions.geometric_cdf
 names = ["header", "table", "priming", "staging", "rounds", "-", "-", "tail"]
+SRC = os.environ.get("HFZ_SRC", "biased")
+K = int(os.environ.get("HFZ_K", "64"))
 for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
-    total = 256 << 20
-    raw = hfz.generate(geometric_cdf(), 1000, total)
-    codec = hfz.BatchCodec(64, total, frame_kib << 10)
+    total = int(os.environ.get("HFZ_MIB", "256")) << 20
+    raw = hfz.generate(hfz.distributions.SOURCES[SRC](), 1000, total)
+    codec = hfz.BatchCodec(K, total, frame_kib << 10)
     batch = codec.compress(raw)
     out = torch.empty(total, dtype=torch.uint8, device="cuda")
     codec.decompress(batch, out); torch.cuda.synchronize()
@@ -28,6 +30,6 @@ for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
     print("  encode cycles/wave %.0f" % (et / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[8 + i] / et)
           for i, n in enumerate(["table+header", "setup", "-", "main loop", "tail"])))
     bt = sum(buf[16:24])
-    print("  build_code ticks(100MHz)/frame %.0f" % (bt / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[16 + i] / max(bt, 1))
-          for i, n in enumerate(["compact", "partition", "rank", "merge", "depths", "limit", "emit"])))
+    print("  build_code cycles/frame %.0f" % (bt / nf), " ".join("%s=%.1f%%" % (n, 100.0 * buf[16 + i] / max(bt, 1))
+          for i, n in enumerate(["compact", "partition", "rank", "merge", "depths", "limit", "emit", "write-out"])))
     print("equal:", bool(torch.equal(out, raw)))
