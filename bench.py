@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="K, streams per frame")
     ap.add_argument("--total-mib", type=int, default=256, help="raw MiB per GPU per step")
-    ap.add_argument("--frame-kib", type=int, default=256, help="raw KiB per frame")
+    ap.add_argument("--frame-kib", type=int, default=128, help="raw KiB per frame")
     ap.add_argument("--source", choices=("biased", "enwik"), default="biased",
                     help="biased: P(i)=0.8^i*0.2 (reference benchmark); enwik: wiki-text-like table")
     ap.add_argument("--shared-table", action="store_true",
@@ -41,7 +41,7 @@ def main():
                          "code built on the device, all frames coded and decoded with it")
     ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
                     help="preset of the named configuration: 2 = K64 256 MiB biased (default), "
-                         "3 = K32 1 GiB enwik-like, 4 = K64 8 GiB/GPU in 1 MiB frames, "
+                         "3 = K32 1 GiB enwik-like in 512 KiB frames, 4 = K64 8 GiB/GPU in 1 MiB frames, "
                          "5 = K64 32 GiB/GPU in 1 MiB frames with a shared table; "
                          "explicit flags given after it win")
     ap.add_argument("--time-every", type=int, default=4,
@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
-    presets = {2: {}, 3: dict(streams=32, total_mib=1024, source="enwik"),
+    presets = {2: {}, 3: dict(streams=32, total_mib=1024, source="enwik", frame_kib=512),
                4: dict(total_mib=8192, frame_kib=1024),
                5: dict(total_mib=32768, frame_kib=1024, shared_table=True)}
     pre, _ = ap.parse_known_args()
