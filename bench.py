@@ -229,6 +229,7 @@ def main():
         single = leg(K, host, frame_bytes, 1, 8.0)
         # the reference's own CPU-runnable case: K = 4, one 100 KiB biased frame
         small = leg(4, host[:100 << 10], 100 << 10, 1, 2.0)
+        k32 = leg(32, host, frame_bytes, 1, 3.0)  # the reference's widest scalar instantiation
         result["cpu_baseline"] = {
             "value": multi["value"], "unit": "MiB/s", "cores": cores, "kind": "port",
             "encode_MiBps": multi["encode_MiBps"], "decode_MiBps": multi["decode_MiBps"],
@@ -239,7 +240,9 @@ def main():
             "single_thread": {"value": single["value"], "encode_MiBps": single["encode_MiBps"],
                               "decode_MiBps": single["decode_MiBps"], "reps": single["reps"]},
             "k4_100KiB_single_thread": {"value": small["value"], "encode_MiBps": small["encode_MiBps"],
-                                        "decode_MiBps": small["decode_MiBps"], "reps": small["reps"]}}
+                                        "decode_MiBps": small["decode_MiBps"], "reps": small["reps"]},
+            "k32_single_thread": {"value": k32["value"], "encode_MiBps": k32["encode_MiBps"],
+                                  "decode_MiBps": k32["decode_MiBps"], "reps": k32["reps"]}}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
