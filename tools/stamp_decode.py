@@ -1,5 +1,10 @@
 """Diagnostic: per-phase cycle shares of decode_kernel (needs tools/libhfz_stamp.so,
-built with -DHFZ_STAMP).  Not part of the product or the tests."""
+built with -DHFZ_STAMP).  Not part of the product or the tests.
+
+Shares of phases that end in global stores (the encoder's tail, the code
+builder's write-out) come out too large: every wave also flushes its timers with
+atomics to a few addresses, and the stores queue behind them.  Check such a
+phase with a build that skips it instead."""
 import ctypes, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
