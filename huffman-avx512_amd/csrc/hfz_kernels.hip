@@ -421,7 +421,34 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
 #pragma unroll
   for (int r = 0; r < 4; ++r) kq[r] = key2[64 * r + lane];
   int ts = 0;
-  {
+  if (n <= 64) {
+    // up to 64 symbols (any skewed source): one register per queue, no blocks
+    int ns = n - 1, nt = 0;
+    uint32_t tw = 0;
+    uint32_t lk = __builtin_amdgcn_readlane(kq[0], ns & 63), nk = 0;
+    while ((ts - nt) + (ns + 1) > 1) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool leaf = ns >= 0 && (nt == ts || lk <= nk);
+        if (leaf) {
+          sum += lk;
+          lparent[ns] = (uint16_t)ts;
+          --ns;
+          lk = __builtin_amdgcn_readlane(kq[0], ns & 63);
+        } else {
+          sum += nk;
+          parent[0][nt] = (uint16_t)ts;
+          ++nt;
+          nk = __builtin_amdgcn_readlane(tw, nt & 63);
+        }
+      }
+      tw = lane == (uint32_t)ts ? sum : tw;
+      if (nt == ts) nk = sum;
+      ++ts;
+    }
+    if (ts > 0) parent[0][ts - 1] = (uint16_t)(ts - 1);
+  } else {
     int ns = n - 1, nt = 0;
     uint32_t kcur = pick4(kq, ns >> 6), tw = 0, tr = 0;
     uint32_t lk = __builtin_amdgcn_readlane(kcur, ns & 63);  // head of the leaf queue
