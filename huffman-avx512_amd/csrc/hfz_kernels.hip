@@ -399,7 +399,8 @@ __device__ __forceinline__ const uint16_t* build_code(const uint32_t* hist, Fram
     for (int d = -15; d <= 15; ++d) {
       const int m = i + d;
       const bool in = m >= 0 && m < n;
-      const uint32_t km = key[in ? m : i];
+      const int mc = m < 0 ? 0 : (m >= n ? n - 1 : m);  // always a valid index: no branch around the read
+      const uint32_t km = key[mc];
       rank += in && (km > k || (km == k && d < 0));
     }
     sym2[rank] = sym[i];
