@@ -1238,9 +1238,9 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // K4 + K5: decode.  The 4096-entry two-symbol table of Decoder2x
 // (codec/huffman.cpp:644-681) is rebuilt in LDS from the frame header, then
 // lane k decodes stream k (CodeReader + Decode, codec/huffman.cpp:502-586,
-// 683-689, 931-953).  Entry layout (u32): byte 0 bits consumed, byte 1 first
-// symbol, byte 2 second symbol (0 if none), byte 3 eight times the symbol
-// count, so that consuming a code is one 64-bit shift by the entry itself and
+// 683-689, 931-953).  Entry layout (u32): byte 0 bits consumed, byte 1 eight
+// times the symbol count, byte 2 first symbol, byte 3 second symbol (0 if
+// none), so that consuming a code is one 64-bit shift by the entry itself and
 // appending its symbols is one shift by a running bit offset.
 //
 // Every lane moves its own stream between global memory and LDS in whole,
@@ -1271,16 +1271,21 @@ constexpr uint32_t kDecOutDw = 16;   // output ring per lane: 64 bytes
 // lookup.  12-bit codes come in sibling pairs that share an 11-bit prefix (the
 // code is complete and they are the numerically last codes), so their entry
 // holds both symbols and the 12th bit picks one (kDecEsc entries).
-constexpr uint32_t kDecEsc = 0x80000000u;
+constexpr uint32_t kDecEsc = 0x80u;
 
-// Entry layout: byte 0 = bits consumed, byte 1 = first symbol, byte 2 = second
-// symbol (0 if none), byte 3 = 8 * number of symbols.  An escape entry has
-// kDecEsc set and the two sibling symbols in bytes 1 and 2; this turns it into
-// a plain one-symbol entry given the window it was looked up with.
+// Entry layout: byte 0 = bits consumed (bits 0..5; bit 7 = kDecEsc), byte 1 =
+// 8 * number of symbols, byte 2 = first symbol, byte 3 = second symbol (0 if
+// none).  An escape entry consumes 12 bits, counts one symbol and carries the
+// two sibling symbols in bytes 2 and 3.  Consuming a code (a 64-bit shift by
+// the entry itself, which looks at bits 0..5 only) therefore never waits for
+// the escape to be resolved; only the extraction of the symbols does: they are
+// the cnt8 bits at offset 16, or at offset 24 for the second sibling, which is
+// one v_bfe_u32 with a computed offset.  This turns an escape entry into a
+// plain one-symbol entry given the window it was looked up with (slow path).
 __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) {
   const uint32_t sel = (uint32_t)(bitbuf >> (63 - 11)) & 1;
-  const uint32_t sym = (e >> (8 + 8 * sel)) & 0xff;
-  return (uint32_t)kMaxCodeLen | (sym << 8) | (8u << 24);
+  const uint32_t sym = (e >> (16 + 8 * sel)) & 0xff;
+  return (uint32_t)kMaxCodeLen | (8u << 8) | (sym << 16);
 }
 
 // kWaves = 1: one frame per wave and workgroup, every frame builds its own table.
@@ -1472,7 +1477,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #pragma unroll 4
         for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
           const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
-          ptab[e] = L | ((uint32_t)syms[j] << 8) | (8u << 24);
+          ptab[e] = L | (8u << 8) | ((uint32_t)syms[j] << 16);
           l1tab[e] = (uint8_t)L;
         }
       }
@@ -1480,14 +1485,14 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         const uint32_t lo = fcode[kMaxCodeLen] >> 1;
         for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
           const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
-          ptab[e] = kDecEsc | (uint32_t)kMaxCodeLen | ((uint32_t)syms[j] << 8) |
-                    ((uint32_t)syms[j + 1] << 16) | (8u << 24);
+          ptab[e] = kDecEsc | (uint32_t)kMaxCodeLen | (8u << 8) | ((uint32_t)syms[j] << 16) |
+                    ((uint32_t)syms[j + 1] << 24);
           l1tab[e] = (uint8_t)kMaxCodeLen;
         }
       }
     }
     HFZ_BARRIER();
-    // second symbol where both codes fit in the index bits.  Byte 1 of an entry
+    // second symbol where both codes fit in the index bits.  Byte 2 of an entry
     // and l1tab never change in this pass, so reading another lane's entry while
     // it is being rewritten is safe.
     if (kF == 1 || p_err == HFZ_OK) {
@@ -1497,7 +1502,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
         const uint32_t L2 = l1tab[rem];
         if (L1 + L2 <= kDecTabBits)
-          ptab[e] = (L1 + L2) | (ptab[e] & 0xff00) | ((ptab[rem] & 0xff00) << 8) | (16u << 24);
+          ptab[e] = (L1 + L2) | (16u << 8) | (ptab[e] & 0xff0000) | ((ptab[rem] & 0xff0000) << 8);
       }
     }
     HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
@@ -1626,15 +1631,22 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   } while (0)
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
-    uint32_t e_ = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];             \
-    /* the compiler turns this into a select (9 VALU); a forced branch      \
-       measured 3-8 % slower */                                             \
-    if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e_ < 0)              \
-      e_ = resolve_escape(e_, bitbuf);                                       \
-    obuf |= (uint64_t)((e_ >> 8) & 0xffff) << sh;                            \
-    sh += e_ >> 24;                                                          \
+    const uint32_t e_ = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];     \
+    const uint32_t cnt8_ = (e_ >> 8) & 0xff;                                 \
+    uint32_t syms_;                                                          \
+    if (kDecTabBits < (uint32_t)kMaxCodeLen) {                               \
+      /* offset 24 iff escape (bit 7 of e_) and the 12th bit (bit 52) is set; \
+         v_bfe_u32 looks at bits 0..4 of the offset, and of those e_ >> 4 can  \
+         only have bit 3 set (consumed < 16, 8 * count is 8 or 16) */        \
+      const uint32_t off_ = (((uint32_t)(bitbuf >> 32) >> 17) & (e_ >> 4)) | 16; \
+      syms_ = __builtin_amdgcn_ubfe(e_, off_, cnt8_);                        \
+    } else {                                                                 \
+      syms_ = e_ >> 16;                                                      \
+    }                                                                        \
+    obuf |= (uint64_t)syms_ << sh;                                           \
+    sh += cnt8_;                                                             \
     bitbuf <<= (e_ & 63);                                                    \
-    used += e_ & 0xff;                                                       \
+    used += e_ & 63;                                                         \
   } while (0)
 #define HFZ_DRAIN()                                                          \
   do {                                                                       \
@@ -1715,9 +1727,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           const uint32_t wa_b = wa;
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
             uint32_t e = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
-            if (kDecTabBits < (uint32_t)kMaxCodeLen && (int32_t)e < 0) e = resolve_escape(e, bitbuf);
-            uint32_t ns = e >> 27;
-            uint32_t pair = (e >> 8) & 0xffff;
+            if (kDecTabBits < (uint32_t)kMaxCodeLen && (e & kDecEsc)) e = resolve_escape(e, bitbuf);
+            uint32_t ns = (e >> 11) & 3;
+            uint32_t pair = e >> 16;
             if (ns > left) {
               ns = 1;
               pair &= 0xff;
@@ -1726,7 +1738,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
             sh += 8 * ns;
             left -= ns;
             bitbuf <<= (e & 63);
-            used += e & 0xff;
+            used += e & 63;
             HFZ_DRAIN();
             if ((j & 3) == 3) HFZ_REFILL();
           }
