@@ -1624,6 +1624,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   // refill: callers that can get there use the guarded form.
 #define HFZ_REFILL()                                                         \
   do {                                                                       \
+    used &= 63; /* whole entries were added; fewer than 64 bits were consumed */ \
     bitbuf |= below >> ((64 - used) & 63);                                   \
     ip -= used >> 3;                                                         \
     used &= 7;                                                               \
@@ -1632,21 +1633,22 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
     const uint32_t e_ = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];     \
-    const uint32_t cnt8_ = (e_ >> 8) & 0xff;                                 \
-    uint32_t syms_;                                                          \
     if (kDecTabBits < (uint32_t)kMaxCodeLen) {                               \
       /* offset 24 iff escape (bit 7 of e_) and the 12th bit (bit 52) is set; \
-         v_bfe_u32 looks at bits 0..4 of the offset, and of those e_ >> 4 can  \
-         only have bit 3 set (consumed < 16, 8 * count is 8 or 16) */        \
+         v_bfe_u32 looks at bits 0..4 of offset and width, and of those      \
+         e_ >> 4 can only have bit 3 set (consumed < 16, 8 * count is 8 or   \
+         16) and e_ >> 8 is 8 * count.  sh collects e_ >> 8 whole: its bits  \
+         0..5 are right, which is all the shift and HFZ_DRAIN look at */     \
+      const uint32_t w_ = e_ >> 8;                                           \
       const uint32_t off_ = (((uint32_t)(bitbuf >> 32) >> 17) & (e_ >> 4)) | 16; \
-      syms_ = __builtin_amdgcn_ubfe(e_, off_, cnt8_);                        \
+      obuf |= (uint64_t)__builtin_amdgcn_ubfe(e_, off_, w_) << (sh & 63);    \
+      sh += w_;                                                              \
     } else {                                                                 \
-      syms_ = e_ >> 16;                                                      \
+      obuf |= (uint64_t)(e_ >> 16) << sh;                                    \
+      sh += (e_ >> 8) & 0xff;                                                \
     }                                                                        \
-    obuf |= (uint64_t)syms_ << sh;                                           \
-    sh += cnt8_;                                                             \
     bitbuf <<= (e_ & 63);                                                    \
-    used += e_ & 63;                                                         \
+    used += e_; /* bits 0..5 of the sum are the bits consumed: HFZ_REFILL */ \
   } while (0)
 #define HFZ_DRAIN()                                                          \
   do {                                                                       \
