@@ -727,22 +727,31 @@ __global__ __launch_bounds__(64) void sizes_kernel(uint32_t K, const uint8_t* __
 constexpr uint32_t kCntThreads = 256;
 constexpr uint32_t kCntBlk = 128;  // bytes per lane per load group (the next group is in flight)
 
+// The lanes of a wave walk streams n/K bytes apart, a power of two for the
+// usual frame sizes, so if they all stood at the same offset of their streams
+// every load would send its 64 lines to the same few memory channels (counting
+// 2 GiB in 1 MiB frames: 0.54 ms that way, 0.42 with streams 16.25 KiB apart).
+// Counting does not care about order, so every lane starts at a block of its
+// own (`rot`) and wraps around.
 __device__ __forceinline__ void count_range(const uint8_t* __restrict__ ibase, uint32_t lo,
-                                            uint32_t hi, uint32_t* col, uint32_t inc) {
+                                            uint32_t hi, uint32_t rot, uint32_t* col, uint32_t inc) {
   if (hi <= lo) return;
   constexpr uint32_t kQ = kCntBlk / 16;  // 16-byte loads per block
   const uint32_t first_blk = lo & ~(kCntBlk - 1);
   const uint32_t nblk = (hi + kCntBlk - 1) / kCntBlk - lo / kCntBlk;
+  uint32_t cur_t = rot % nblk;  // block being counted; the next one is in flight
   uint4 cur[kQ], nxt[kQ];
 #pragma unroll
-  for (uint32_t q = 0; q < kQ; ++q) nxt[q] = *(const uint4*)(ibase + first_blk + 16 * q);
+  for (uint32_t q = 0; q < kQ; ++q) nxt[q] = *(const uint4*)(ibase + first_blk + kCntBlk * cur_t + 16 * q);
   for (uint32_t t = 0; t < nblk; ++t) {
-    const uint32_t b = first_blk + kCntBlk * t;
+    const uint32_t b = first_blk + kCntBlk * cur_t;
 #pragma unroll
     for (uint32_t q = 0; q < kQ; ++q) cur[q] = nxt[q];
+    cur_t = cur_t + 1 == nblk ? 0 : cur_t + 1;
     if (t + 1 < nblk) {
 #pragma unroll
-      for (uint32_t q = 0; q < kQ; ++q) nxt[q] = *(const uint4*)(ibase + b + kCntBlk + 16 * q);
+      for (uint32_t q = 0; q < kQ; ++q)
+        nxt[q] = *(const uint4*)(ibase + first_blk + kCntBlk * cur_t + 16 * q);
     }
     if (b >= lo && b + kCntBlk <= hi) {
 #pragma unroll
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
       const uint32_t in0 = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
       const uint32_t colidx = packed ? stream & 31 : stream + K * (part % reps);
       const uint32_t inc = packed ? 1u << (16 * (stream >> 5)) : 1u;
-      count_range(ibase, in0 + rel_lo, in0 + rel_hi, cnt + colidx, inc);
+      count_range(ibase, in0 + rel_lo, in0 + rel_hi, 2 * stream + part, cnt + colidx, inc);
     }
   }
   __syncthreads();
