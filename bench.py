@@ -9,6 +9,10 @@ the same size (independent frames, no data-path collective): weak scaling.
 Prints one JSON line (rank 0).  `value` = raw MiB that went through encode AND
 decode per second, whole job: N * total / (time per step).  MiB = 2^20 bytes of
 RAW data, the reference's convention (codec/huffman_benchmark.cpp:67,78).
+
+The job bookkeeping (barrier, max-over-ranks time, the one exchange of the
+shared-table mode) lives in functions of its own so that the world_size-2 gloo
+test drives the same code on CPU (tests/test_multirank.py).
 """
 import argparse
 import importlib
@@ -17,13 +21,92 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+METRIC = "MiB/s encode+decode on 256-sym biased input; achieved HBM GB/s vs peak"
+
+
+# ---- job bookkeeping (runs under gloo on CPU as well) -------------------------
+
+def job_barrier(world, cuda):
+    """Device idle on every rank, then all ranks together, then idle again."""
+    import torch
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world, device):
+    """The slowest rank's time: what the whole job took."""
+    if world <= 1:
+        return float(seconds)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_histogram(hfz, h, world):
+    """The shared-table mode's one exchange: the ranks' 256 byte counts (int64
+    tensor, 2 KiB per GPU) are summed, then scaled to what the 32-bit code
+    builders take.  Returns the int32 tensor of uint32 bit patterns, identical on
+    every rank."""
+    h = h.clone()
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(h)
+    return hfz.scale_histogram_dev(h)
+
+
+def time_steps(step, steps, warmup, world, cuda, device):
+    """`warmup` untimed steps, then exactly `steps` steps between two job barriers;
+    returns (seconds of the slowest rank, what the last step returned)."""
+    last = None
+    for _ in range(warmup):
+        last = step()
+    job_barrier(world, cuda)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    job_barrier(world, cuda)
+    elapsed = time.perf_counter() - t0
+    return max_over_ranks(elapsed, world, device), last
+
+
+def job_value(world, mib_per_rank, elapsed, steps):
+    """Whole-job raw MiB per second (every rank processed mib_per_rank per step)."""
+    return world * mib_per_rank / (elapsed / steps)
+
+
+# ---- the benchmark ---------------------------------------------------------------
+
+def kernel_table(kt, alg_bytes, shared_table):
+    """Per-kernel mean launch times with the algorithmic rate of those that moved
+    data.  A kernel the library did not run in this mode gets ms = None, no rate."""
+    ran = {"hist": (kt["count_calls"] > 0) if shared_table else kt["hist_ms"] > 0.002,
+           "table": kt["table_ms"] > 0.002, "sizes": kt["sizes_ms"] > 0.02,
+           "place": True, "encode": True, "decode": True}
+    ms_of = dict((n, kt[n + "_ms"]) for n in ran)
+    if shared_table:
+        ms_of["hist"] = kt["count_ms"]  # the input pass is hfz_count_batch_dev's
+    out = {}
+    for name in ("hist", "table", "sizes", "place", "encode", "decode"):
+        if not ran[name]:
+            out[name] = {"ms": None}
+            continue
+        ent = {"ms": round(ms_of[name], 4)}
+        if name in alg_bytes and ms_of[name] > 0:
+            ent["GBps"] = round(alg_bytes[name] / (ms_of[name] * 1e-3) / 1e9, 1)
+        out[name] = ent
+    return out, ms_of, ran
 
 
 def main():
@@ -74,7 +157,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     hfz = importlib.import_module("huffman-avx512_amd")
-    hfz.lib()  # fails loudly if the HIP library is missing
+    L = hfz.lib()  # fails loudly if the HIP library is missing
 
     K = args.streams
     total = args.total_mib << 20
@@ -83,23 +166,15 @@ def main():
     raw = hfz.generate(cdf, 1000 + rank, total, device=dev)
     codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
-
-    L = hfz.lib()
     code = torch.zeros(792, dtype=torch.uint8, device=dev)
 
     def shared_code():
         # one pass over the batch leaves per-stream counts in the workspace and the
-        # 256 byte counts here; those are summed over ranks: the job's one exchange,
-        # 2 KiB per GPU
-        st = torch.cuda.current_stream(dev).cuda_stream
-        h = codec.count(raw).clone()
-        if world > 1:
-            dist.all_reduce(h)
-        # counts beyond 32 bits are scaled down, every occurring symbol stays nonzero
-        shift = torch.clamp(torch.floor(torch.log2(h.max().clamp(min=1).double())) - 31, min=0).long()
-        h = torch.where(h > 0, torch.clamp(h >> shift, min=1), h)
-        h32 = (h & 0xffffffff).to(torch.int32)  # bit pattern of the unsigned count
-        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, code.data_ptr(), st)
+        # 256 byte counts in a device tensor; those are summed over ranks (the job's
+        # one exchange) and the code is built on the device from the sum
+        h32 = job_histogram(hfz, codec.count(raw), world)
+        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, code.data_ptr(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
         assert rc == 0, rc
         return code
 
@@ -112,29 +187,13 @@ def main():
             codec.decompress(batch, out)
         return batch
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    job_barrier(world, True)
     hfz.timing_enable(max(1, min(args.time_every, args.steps)))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch = step()
-    barrier()
-    t1 = time.perf_counter()
+    elapsed, batch = time_steps(step, args.steps, 0, world, True, dev)
     kt = hfz.timing_read()
     hfz.timing_enable(False)
-
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # correctness of what was timed
     assert torch.equal(out, raw), "round trip mismatch"
@@ -143,22 +202,14 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     mib = total / float(1 << 20)
-    value = world * mib / (elapsed / args.steps)
+    value = job_value(world, mib, elapsed, args.steps)
 
     # per-kernel roofline: algorithmic HBM bytes per launch / mean launch time
     N, C = float(total), float(comp_bytes)
     alg_bytes = {"hist": N, "sizes": N, "encode": N + C, "decode": C + N}
-    kernels = {}
-    for name in ("hist", "table", "sizes", "place", "encode", "decode"):
-        ms = kt[name + "_ms"]
-        ent = {"ms": round(ms, 4)}
-        # sizes_ms is the gap between two adjacent events when the input pass already
-        # gave the stream sizes: no kernel ran, so no rate
-        if name in alg_bytes and ms > (0.02 if name == "sizes" else 0):
-            ent["GBps"] = round(alg_bytes[name] / (ms * 1e-3) / 1e9, 1)
-        kernels[name] = ent
-    dom = max(("hist", "sizes", "encode", "decode"), key=lambda k: kt[k + "_ms"])
-    achieved = alg_bytes[dom] / (kt[dom + "_ms"] * 1e-3) / 1e9 if kt[dom + "_ms"] > 0 else 0.0
+    kernels, ms_of, ran = kernel_table(kt, alg_bytes, args.shared_table)
+    dom = max((k for k in ("hist", "sizes", "encode", "decode") if ran[k]), key=lambda k: ms_of[k])
+    achieved = alg_bytes[dom] / (ms_of[dom] * 1e-3) / 1e9 if ms_of[dom] > 0 else 0.0
     traffic = None
     try:  # PMC passes are separate rocprofv3 runs; use them only for the same workload
         with open(args.traffic_json) as f:
@@ -172,16 +223,18 @@ def main():
             traffic = prof.get(dom + "_kernel")
     except (OSError, ValueError):
         pass
-    enc_ms = sum(kt[k + "_ms"] for k in ("hist", "table", "sizes", "place", "encode"))
+    enc_ms = sum(ms_of[k] for k in ("hist", "table", "sizes", "place", "encode") if ran[k])
+    launches = {"decode": kt["decompress_calls"],
+                "hist": kt["count_calls"] if args.shared_table else kt["compress_calls"]}
     roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes[dom]),
-                "launch_ms": round(kt[dom + "_ms"], 4),
-                "launches_timed": int(kt["decompress_calls"] if dom == "decode" else kt["compress_calls"])}
+                "launch_ms": round(ms_of[dom], 4),
+                "launches_timed": int(launches.get(dom, kt["compress_calls"]))}
 
     result = {
-        "metric": "MiB/s encode+decode on 256-sym biased input; achieved HBM GB/s vs peak",
+        "metric": METRIC,
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -197,6 +250,7 @@ def main():
                    "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
                    "frames_per_gpu": codec.n_frames, "compressed_over_raw": round(C / N, 4),
                    "layout": "packed"},
+        # sums of kernel times, the input pass of the shared-table mode included
         "encode_MiBps_kernels": round(mib / (enc_ms * 1e-3), 1) if enc_ms > 0 else None,
         "decode_MiBps_kernels": round(mib / (kt["decode_ms"] * 1e-3), 1) if kt["decode_ms"] > 0 else None,
         "kernels": kernels,
@@ -204,49 +258,52 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # The oracle (scalar C restatement of the reference, test infrastructure) on the
-        # host cores of this box, whole-call compress + decompress per frame like the
-        # reference's benchmark; a bounded sample of the same batch (~10 s per leg).
-        import oracle
-        sample = min(total, 32 << 20)
-        host = raw[:sample].cpu().numpy()
-        smib1 = sample / float(1 << 20)
-        try:
-            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-        except ValueError:
-            cores = min(16, os.cpu_count() or 1)
-        cores = max(1, min(cores, 64))
-
-        def leg(K_, data, fb, threads, seconds):
-            tc, td, _ = oracle.time_roundtrip(K_, data, fb, 1, threads)
-            reps = int(max(1, min(2000, round(seconds / max(tc + td, 1e-4)))))
-            tc, td, _ = oracle.time_roundtrip(K_, data, fb, reps, threads)
-            m = reps * len(data) / float(1 << 20)
-            return {"value": round(m / (tc + td), 1), "encode_MiBps": round(m / tc, 1),
-                    "decode_MiBps": round(m / td, 1), "reps": reps}
-
-        multi = leg(K, host, frame_bytes, cores, 8.0)
-        single = leg(K, host, frame_bytes, 1, 8.0)
-        # the reference's own CPU-runnable case: K = 4, one 100 KiB biased frame
-        small = leg(4, host[:100 << 10], 100 << 10, 1, 2.0)
-        k32 = leg(32, host, frame_bytes, 1, 3.0)  # the reference's widest scalar instantiation
-        result["cpu_baseline"] = {
-            "value": multi["value"], "unit": "MiB/s", "cores": cores, "kind": "port",
-            "encode_MiBps": multi["encode_MiBps"], "decode_MiBps": multi["decode_MiBps"],
-            "sample": "first %d MiB of rank 0's batch (%d frames of %d KiB, K=%d), %d repetitions of "
-                      "whole-call compress+decompress with the scalar C restatement of the "
-                      "reference, frames spread over %d threads" % (
-                          sample >> 20, sample // frame_bytes, args.frame_kib, K, multi["reps"], cores),
-            "single_thread": {"value": single["value"], "encode_MiBps": single["encode_MiBps"],
-                              "decode_MiBps": single["decode_MiBps"], "reps": single["reps"]},
-            "k4_100KiB_single_thread": {"value": small["value"], "encode_MiBps": small["encode_MiBps"],
-                                        "decode_MiBps": small["decode_MiBps"], "reps": small["reps"]},
-            "k32_single_thread": {"value": k32["value"], "encode_MiBps": k32["encode_MiBps"],
-                                  "decode_MiBps": k32["decode_MiBps"], "reps": k32["reps"]}}
+        result["cpu_baseline"] = cpu_baseline(raw, total, K, frame_bytes, args.frame_kib)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline(raw, total, K, frame_bytes, frame_kib):
+    """The oracle (scalar C restatement of the reference, test infrastructure) on the
+    host cores of this box, whole-call compress + decompress per frame like the
+    reference's benchmark; a bounded sample of the same batch (~10 s per leg)."""
+    import oracle
+    sample = min(total, 32 << 20)
+    host = raw[:sample].cpu().numpy()
+    try:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    except ValueError:
+        cores = min(16, os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+
+    def leg(K_, data, fb, threads, seconds):
+        tc, td, _ = oracle.time_roundtrip(K_, data, fb, 1, threads)
+        reps = int(max(1, min(2000, round(seconds / max(tc + td, 1e-4)))))
+        tc, td, _ = oracle.time_roundtrip(K_, data, fb, reps, threads)
+        m = reps * len(data) / float(1 << 20)
+        return {"value": round(m / (tc + td), 1), "encode_MiBps": round(m / tc, 1),
+                "decode_MiBps": round(m / td, 1), "reps": reps}
+
+    multi = leg(K, host, frame_bytes, cores, 8.0)
+    single = leg(K, host, frame_bytes, 1, 8.0)
+    # the reference's own CPU-runnable case: K = 4, one 100 KiB biased frame
+    small = leg(4, host[:100 << 10], 100 << 10, 1, 2.0)
+    k32 = leg(32, host, frame_bytes, 1, 3.0)  # the reference's widest scalar instantiation
+    return {
+        "value": multi["value"], "unit": "MiB/s", "cores": cores, "kind": "port",
+        "encode_MiBps": multi["encode_MiBps"], "decode_MiBps": multi["decode_MiBps"],
+        "sample": "first %d MiB of rank 0's batch (%d frames of %d KiB, K=%d), %d repetitions of "
+                  "whole-call compress+decompress with the scalar C restatement of the "
+                  "reference, frames spread over %d threads" % (
+                      sample >> 20, sample // frame_bytes, frame_kib, K, multi["reps"], cores),
+        "single_thread": {"value": single["value"], "encode_MiBps": single["encode_MiBps"],
+                          "decode_MiBps": single["decode_MiBps"], "reps": single["reps"]},
+        "k4_100KiB_single_thread": {"value": small["value"], "encode_MiBps": small["encode_MiBps"],
+                                    "decode_MiBps": small["decode_MiBps"], "reps": small["reps"]},
+        "k32_single_thread": {"value": k32["value"], "encode_MiBps": k32["encode_MiBps"],
+                              "decode_MiBps": k32["decode_MiBps"], "reps": k32["reps"]}}
 
 
 if __name__ == "__main__":

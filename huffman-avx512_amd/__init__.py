@@ -58,7 +58,8 @@ class HfzError(RuntimeError):
 class BatchTiming(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in
                 ("hist_ms", "table_ms", "sizes_ms", "place_ms", "encode_ms", "decode_ms")] + [
-                    ("compress_calls", ctypes.c_int32), ("decompress_calls", ctypes.c_int32)]
+                    ("compress_calls", ctypes.c_int32), ("decompress_calls", ctypes.c_int32),
+                    ("count_ms", ctypes.c_float), ("count_calls", ctypes.c_int32)]
 
 
 class FrameCode(ctypes.Structure):
@@ -216,16 +217,32 @@ def histogram_dev(raw):
 
 
 def scale_histogram(hist):
-    """256 counts of any width -> uint32 counts for the code builder: while the
-    largest count needs more than 32 bits all counts are halved (floor), but a
-    symbol that occurs at all keeps a count of at least 1, so it keeps a code."""
+    """256 counts of any width -> uint32 counts for the code builder.  The builders
+    (host, device and the reference's MakeCanonicalCoding, codec/huffman.cpp:364-416)
+    add node counts in 32 bits, which is exact only while the SUM of the counts
+    stays below 2^32 (the reference's frames are below 4 GiB, so it always does
+    there).  All counts are therefore shifted right until the sum is below 2^31;
+    a symbol that occurs at all keeps a count of at least 1, so it keeps a code
+    (that adds at most 255 to the sum)."""
     h = np.asarray(hist, dtype=np.uint64).reshape(256)
-    shift = 0
-    while (int(h.max(initial=0)) >> shift) > 0xffffffff:
-        shift += 1
+    shift = max(0, int(h.sum(dtype=np.uint64)).bit_length() - 31)
     if shift:
         h = np.where(h > 0, np.maximum(h >> np.uint64(shift), np.uint64(1)), np.uint64(0))
     return h.astype(np.uint32)
+
+
+def scale_histogram_dev(h):
+    """scale_histogram for a device (or host) int64 tensor of 256 counts, without
+    a host round trip; returns the int32 tensor holding the uint32 bit patterns,
+    ready for hfz_build_codes_dev."""
+    import torch
+    assert h.dtype == torch.int64 and h.numel() == 256
+    total = h.sum()
+    # bit_length(total) - 31, at least 0: number of k in 31..62 with total >> k != 0
+    ks = torch.arange(31, 63, dtype=torch.int64, device=h.device)
+    shift = ((total >> ks) > 0).sum()
+    scaled = torch.where(h > 0, torch.clamp(h >> shift, min=1), h)
+    return scaled.to(torch.int32)
 
 
 def build_code_table(hist):

@@ -204,6 +204,16 @@ int decompress_file(const char* in_path, const char* out_path, uint64_t batch_by
     const uint64_t raw0 = f0 * frame_bytes;
     const uint64_t n = raw_bytes - raw0 < nf * (uint64_t)frame_bytes ? raw_bytes - raw0
                                                                      : nf * (uint64_t)frame_bytes;
+    // A frame's header (word 0 = raw size) must claim exactly the bytes the
+    // container gives it: frame_bytes, or what is left for the last frame.  The
+    // device only refuses a frame that claims MORE than its room; one that
+    // claims less would decode "ok" and leave stale bytes in the output.
+    for (uint64_t i = 0; i < nf; ++i) {
+      const uint64_t at = (f0 + i) * (uint64_t)frame_bytes;
+      const uint64_t expect = raw_bytes - at < frame_bytes ? raw_bytes - at : frame_bytes;
+      if (all_sizes[f0 + i] < 8 || get32(&comp[offs[i]]) != expect)
+        die("corrupt frame (raw size in the frame header differs from the container's)");
+    }
     hip_ok(hipMemcpy(d_comp.p, comp.data(), bytes, hipMemcpyHostToDevice), "copy in");
     hip_ok(hipMemcpy(d_off.p, offs.data(), 8 * nf, hipMemcpyHostToDevice), "copy offsets");
     hip_ok(hipMemcpy(d_size.p, &all_sizes[f0], 4 * nf, hipMemcpyHostToDevice), "copy sizes");
@@ -218,8 +228,6 @@ int decompress_file(const char* in_path, const char* out_path, uint64_t batch_by
       hip_ok(hipMemcpy(host.data(), d_raw.p, n, hipMemcpyDeviceToHost), "copy out");
       if (n && std::fwrite(host.data(), 1, n, out) != n) die("write failed", out_path);
     }
-    // a frame's header must claim exactly the bytes the container gives it
-    // (checked on the device: raw size > room is refused); the last frame may be short
   }
   if (out) std::fclose(out);
   std::fclose(in);

@@ -32,13 +32,26 @@ int hip_fail(hipError_t e) {
 // sets taken since the last read.  Events between kernels keep one kernel's
 // tail from overlapping the next one's start, which costs a few percent of a
 // short batch: sampling keeps the measurement and most of the overlap.
-constexpr int kEncEvents = 6, kDecEvents = 2, kMaxTimedCalls = 512;
+constexpr int kEncEvents = 6, kDecEvents = 2, kCntEvents = 2, kMaxTimedCalls = 512;
 struct Timing {
-  int every = 0;                     // 0 = off
-  std::vector<hipEvent_t> enc, dec;  // kEncEvents / kDecEvents per timed call
-  size_t enc_calls = 0, dec_calls = 0;  // timed calls
-  size_t enc_seen = 0, dec_seen = 0;    // all calls while on
+  int every = 0;                          // 0 = off
+  std::vector<hipEvent_t> enc, dec, cnt;  // kEncEvents / kDecEvents / kCntEvents per timed call
+  size_t enc_calls = 0, dec_calls = 0, cnt_calls = 0;  // timed calls
+  size_t enc_seen = 0, dec_seen = 0, cnt_seen = 0;     // all calls while on
   hipEvent_t* cur = nullptr;
+  void reset_window() {
+    enc_calls = dec_calls = cnt_calls = 0;
+    enc_seen = dec_seen = cnt_seen = 0;
+    cur = nullptr;
+  }
+  // Called when timing is switched off: the events go back to the runtime (a
+  // destructor at thread or process exit could run after HIP has shut down).
+  void release() {
+    for (auto* v : {&enc, &dec, &cnt}) {
+      for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+      v->clear();
+    }
+  }
   hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, size_t& seen, int per_call) {
     cur = nullptr;
     if (every <= 0) return hipSuccess;
@@ -60,6 +73,10 @@ hipError_t mark(int i, hipStream_t st) {
   if (!g_timing.cur) return hipSuccess;
   return hipEventRecord(g_timing.cur[i], st);
 }
+
+// The kernels read histograms and counters with 16-byte vector loads and carve
+// the workspace on 256-byte boundaries.
+bool misaligned(const void* p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
 bool have_device() {
   int n = 0;
@@ -90,6 +107,8 @@ void limit_code_lengths(uint32_t* len_count, int max_seen) {
 }
 
 }  // namespace
+
+int hip_failure(int hip_error) { return hip_fail((hipError_t)hip_error); }
 
 // MakeCanonicalCoding, codec/huffman.cpp:339-437.  The symbol order comes from
 // the same std::sort call on the same initial sequence with the same
@@ -235,7 +254,7 @@ size_t hfz_workspace_bytes(int K, size_t n_frames) {
 
 int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes, uint32_t* d_hist,
                             void* stream) {
-  if (!d_hist || frame_bytes == 0 || (total && !d_raw)) return HFZ_E_ARG;
+  if (!d_hist || frame_bytes == 0 || (total && !d_raw) || misaligned(d_hist, 4)) return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
   const size_t nf = hfz_batch_frames(total, frame_bytes);
   HFZ_HIP(launch_histogram((const uint8_t*)d_raw, total, frame_bytes, nf, d_hist, stream));
@@ -244,15 +263,26 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
 
 int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream) {
   if (!d_hist || (n && !d_src)) return HFZ_E_ARG;
-  // one "frame" covering everything; counts wrap at 2^32 like the u32 bins of
-  // ByteHistogram (codec/histogram.h:10)
-  HFZ_HIP(launch_histogram((const uint8_t*)d_src, n, n ? n : 1, 1, d_hist, stream));
+  if (((uintptr_t)d_hist & 3) != 0) return HFZ_E_ARG;
+  // Counts wrap at 2^32 like the u32 bins of ByteHistogram (codec/histogram.h:10).
+  // The kernel's frame length is 32 bits wide, so a large buffer is counted in
+  // pieces of at most 1 GiB, each added to the same 256 counters.
+  constexpr size_t kPiece = size_t(1) << 30;
+  if (n <= kPiece) {
+    HFZ_HIP(launch_histogram((const uint8_t*)d_src, n, n ? n : 1, 1, d_hist, stream));
+    return HFZ_OK;
+  }
+  HFZ_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), (hipStream_t)stream));
+  for (size_t lo = 0; lo < n; lo += kPiece) {
+    const size_t len = n - lo < kPiece ? n - lo : kPiece;
+    HFZ_HIP(launch_histogram((const uint8_t*)d_src + lo, len, len, 1, d_hist, stream, true));
+  }
   return HFZ_OK;
 }
 
 }  // extern "C" (reopened below)
 
-namespace {
+namespace hfz {
 
 // d_shared == nullptr: every frame gets its own code (the reference's
 // CompressMulti<K>); otherwise all frames are coded with *d_shared.
@@ -265,6 +295,9 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
   if (comp_stride && comp_stride < hfz_compress_bound(frame_bytes, K)) return HFZ_E_ARG;
+  if (misaligned(d_ws, 256) || misaligned(d_comp_off, 8) || misaligned(d_comp_size, 4) ||
+      misaligned(d_status, 4) || misaligned(d_shared, 4))
+    return HFZ_E_ARG;
   const size_t nf = hfz_batch_frames(total, frame_bytes);
   const WorkspaceLayout w = workspace_layout(nf);
   if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
@@ -312,11 +345,17 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
   return HFZ_OK;
 }
 
+}  // namespace hfz
+
+namespace {
+
 int decompress_batch(int K, const void* d_comp, size_t comp_bytes, const uint64_t* d_comp_off,
                      const uint32_t* d_comp_size, size_t n_frames, void* d_raw, size_t raw_cap,
                      size_t frame_bytes, int32_t* d_status, bool shared, void* stream) {
   if (K < 1 || K > HFZ_MAX_STREAMS || !d_comp || !d_comp_off || !d_comp_size || frame_bytes == 0 ||
       (raw_cap && !d_raw))
+    return HFZ_E_ARG;
+  if (misaligned(d_comp_off, 8) || misaligned(d_comp_size, 4) || misaligned(d_status, 4))
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
   HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, g_timing.dec_seen, kDecEvents));
@@ -348,15 +387,21 @@ int hfz_count_batch_dev(int K, const void* d_raw, size_t total, size_t frame_byt
   const size_t nf = hfz_batch_frames(total, frame_bytes);
   const WorkspaceLayout w = workspace_layout(nf);
   if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
+  if (misaligned(d_ws, 256) || misaligned(d_hist_total, 8)) return HFZ_E_ARG;
   uint8_t* ws = (uint8_t*)d_ws;
   uint32_t* d_hist = (uint32_t*)(ws + w.hist);
   const uint8_t* raw = (const uint8_t*)d_raw;
+  hipStream_t st = (hipStream_t)stream;
+  HFZ_HIP(g_timing.take(g_timing.cnt, g_timing.cnt_calls, g_timing.cnt_seen, kCntEvents));
+  HFZ_HIP(mark(0, st));
   if (count_kernel_fits(K, frame_bytes)) {
     HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, false, (uint32_t*)(ws + w.counts),
                          d_hist, (uint32_t*)(ws + w.stream_end), (uint32_t*)(ws + w.csize), stream));
   } else {
     HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
   }
+  HFZ_HIP(mark(1, st));  // count_ms is the input pass alone; the 256-bin reduction below is not in it
+  g_timing.cur = nullptr;
   HFZ_HIP(launch_hist_total(d_hist, nf, d_hist_total, stream));
   return HFZ_OK;
 }
@@ -370,6 +415,9 @@ int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
   if (comp_stride && comp_stride < hfz_compress_bound(frame_bytes, K)) return HFZ_E_ARG;
+  if (misaligned(d_ws, 256) || misaligned(d_comp_off, 8) || misaligned(d_comp_size, 4) ||
+      misaligned(d_status, 4) || misaligned(d_code, 4))
+    return HFZ_E_ARG;
   const size_t nf = hfz_batch_frames(total, frame_bytes);
   const WorkspaceLayout w = workspace_layout(nf);
   if (ws_bytes < w.total) return HFZ_E_WORKSPACE;
@@ -429,7 +477,7 @@ int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes
 
 int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_codes, void* stream) {
   static_assert(sizeof(hfz_frame_code) == sizeof(FrameCode), "public and internal layout differ");
-  if (!d_hist || !d_codes) return HFZ_E_ARG;
+  if (!d_hist || !d_codes || misaligned(d_hist, 16) || misaligned(d_codes, 4)) return HFZ_E_ARG;
   HFZ_HIP(launch_build_codes(d_hist, n, (FrameCode*)d_codes, stream));
   return HFZ_OK;
 }
@@ -461,9 +509,8 @@ int hfz_set_encoder_block(int bytes) {
 int hfz_timing_enable(int every) {
   if (every < 0) return HFZ_E_ARG;
   g_timing.every = every;
-  g_timing.enc_calls = g_timing.dec_calls = 0;
-  g_timing.enc_seen = g_timing.dec_seen = 0;
-  g_timing.cur = nullptr;
+  g_timing.reset_window();
+  if (every == 0) g_timing.release();
   return HFZ_OK;
 }
 
@@ -488,13 +535,21 @@ int hfz_timing_read(hfz_batch_timing* out) {
     HFZ_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out->decode_ms += ms;
   }
+  for (size_t c = 0; c < g_timing.cnt_calls; ++c) {
+    hipEvent_t* ev = &g_timing.cnt[c * kCntEvents];
+    HFZ_HIP(hipEventSynchronize(ev[1]));
+    float ms = 0;
+    HFZ_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out->count_ms += ms;
+  }
   if (g_timing.enc_calls)
     for (int i = 0; i < 5; ++i) *dst[i] /= (float)g_timing.enc_calls;
   if (g_timing.dec_calls) out->decode_ms /= (float)g_timing.dec_calls;
+  if (g_timing.cnt_calls) out->count_ms /= (float)g_timing.cnt_calls;
   out->compress_calls = (int32_t)g_timing.enc_calls;
   out->decompress_calls = (int32_t)g_timing.dec_calls;
-  g_timing.enc_calls = g_timing.dec_calls = 0;
-  g_timing.enc_seen = g_timing.dec_seen = 0;
+  out->count_calls = (int32_t)g_timing.cnt_calls;
+  g_timing.reset_window();
   return HFZ_OK;
 }
 

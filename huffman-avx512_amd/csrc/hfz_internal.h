@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/hfz.h"
 
 namespace hfz {
@@ -52,19 +54,32 @@ inline WorkspaceLayout workspace_layout(size_t n) {
   return w;
 }
 
+// Process-wide tuning knobs; any thread may set them while others launch, so they
+// are atomics (relaxed: a launch sees the old or the new value, both are valid).
 // 0 = choose by frame count, 11 / 12 = forced (hfz_set_decoder_table_bits).
-extern int g_decoder_table_bits;
+extern std::atomic<int> g_decoder_table_bits;
 // 0 = choose by frame count, 1 / 2 = forced (hfz_set_frames_per_wave).
-extern int g_frames_per_wave;
+extern std::atomic<int> g_frames_per_wave;
 // 0 = choose by frame count, 32 / 64 = forced (hfz_set_encoder_block).
-extern int g_encoder_block;
+extern std::atomic<int> g_encoder_block;
 
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);
 
+// The batch encoder behind hfz_compress_batch_dev and its variants (hfz_host.cpp):
+// argument checks, workspace carve-up, kernel sequence.  d_shared == nullptr:
+// every frame gets its own code.  Calls no allocating routine while kernel
+// timing (hfz_timing_enable) is off.
+int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, void* d_comp,
+                   size_t comp_cap, size_t comp_stride, uint64_t* d_comp_off,
+                   uint32_t* d_comp_size, int32_t* d_status, void* d_ws, size_t ws_bytes,
+                   const FrameCode* d_shared, void* stream);
+// Records the text of a failed HIP call for hfz_last_hip_error and maps it to an HFZ_E_* code.
+int hip_failure(int hip_error);
+
 // Kernel launchers (hfz_kernels.hip).  All return a hipError_t as int.
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                     uint64_t n_frames, uint32_t* d_hist, void* stream);
+                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate = false);
 int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream);
 // d_hist != nullptr: also builds d_code[f] from d_hist[f] (separate-pass encoder);
 // d_hist == nullptr: d_code is given, per frame or (shared_code) one for all frames.

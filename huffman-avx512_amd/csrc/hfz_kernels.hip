@@ -103,7 +103,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
 // over 8 arrays for the same reason (codec/histogram.cpp:18).
 __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ raw,
                                                    uint64_t total, uint64_t frame_bytes,
-                                                   uint32_t bpf, uint32_t* __restrict__ hist) {
+                                                   uint32_t bpf, uint32_t accumulate,
+                                                   uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256 * 8];
   const uint32_t tid = threadIdx.x;
   const uint64_t f = blockIdx.x / bpf;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ r
   uint32_t sum = 0;
 #pragma unroll
   for (int r = 0; r < 8; ++r) sum += h[tid * 8 + r];
-  if (bpf == 1)
+  if (bpf == 1 && !accumulate)
     hist[f * 256 + tid] = sum;
   else if (sum)
     atomicAdd(&hist[f * 256 + tid], sum);
@@ -1878,26 +1879,29 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 }  // namespace
 
-int g_decoder_table_bits = 0;
-int g_frames_per_wave = 0;
-int g_encoder_block = 0;
+std::atomic<int> g_decoder_table_bits{0};
+std::atomic<int> g_frames_per_wave{0};
+std::atomic<int> g_encoder_block{0};
 
 // ---------------------------------------------------------------------------
 // launchers
 
+// accumulate: the counts are added to what d_hist holds (the caller cleared it).
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                     uint64_t n_frames, uint32_t* d_hist, void* stream) {
+                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate) {
   if (n_frames == 0) return hipSuccess;
+  if (frame_bytes > 0xffffffffull) return hipErrorInvalidValue;  // frame_len() is 32 bits wide
   uint64_t bpf = (frame_bytes + (1u << 16) - 1) >> 16;  // ~64 KiB of input per block
   if (bpf < 1) bpf = 1;
   if (bpf > 65536) bpf = 65536;
   if (n_frames * bpf > 0x7fffffffull) return hipErrorInvalidValue;
-  if (bpf > 1) {
+  if (bpf > 1 && !accumulate) {
     hipError_t e = hipMemsetAsync(d_hist, 0, n_frames * 256 * sizeof(uint32_t), as_stream(stream));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(hist_kernel, dim3((uint32_t)(n_frames * bpf)), dim3(256), 0,
-                     as_stream(stream), d_raw, total, frame_bytes, (uint32_t)bpf, d_hist);
+                     as_stream(stream), d_raw, total, frame_bytes, (uint32_t)bpf,
+                     accumulate ? 1u : 0u, d_hist);
   return hipGetLastError();
 }
 
@@ -1969,8 +1973,9 @@ int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t co
 int device_cus();
 // two frames per wave once the pairs still give every SIMD a wave
 bool pair_frames(int K, uint64_t n_frames) {
-  if (K > 32 || g_frames_per_wave == 1) return false;
-  return g_frames_per_wave == 2 || n_frames > 4 * (uint64_t)device_cus();
+  const int fpw = g_frames_per_wave.load(std::memory_order_relaxed);
+  if (K > 32 || fpw == 1) return false;
+  return fpw == 2 || n_frames > 4 * (uint64_t)device_cus();
 }
 
 int device_cus() {
@@ -1988,8 +1993,9 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   const bool pair = pair_frames(K, n_frames);
-  const bool wide = g_encoder_block ? g_encoder_block == 64
-                                    : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
+  const int enc_blk = g_encoder_block.load(std::memory_order_relaxed);
+  const bool wide = enc_blk ? enc_blk == 64
+                            : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
   const dim3 grid((uint32_t)(pair ? (n_frames + 1) / 2 : n_frames));
 #define HFZ_LAUNCH_ENCODE(F, B)                                                                  \
   hipLaunchKernelGGL((encode_kernel<F, B>), grid, dim3(64), 0, as_stream(stream), (uint32_t)K,  \
@@ -2029,14 +2035,15 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
   // costs less than the extra resident waves return.
   const int cus = device_cus();
-  if (g_decoder_table_bits != 12 && pair_frames(K, n_frames)) {
+  const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
+  if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
     hipLaunchKernelGGL((decode_kernel<11, 1, 2, false>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
     return hipGetLastError();
   }
-  const bool wide = g_decoder_table_bits ? g_decoder_table_bits == 12 : n_frames <= (uint64_t)cus * 5;
+  const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
     hipLaunchKernelGGL((decode_kernel<12, 1, 1, false>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,

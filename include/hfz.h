@@ -122,6 +122,11 @@ int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_code
  * All d_* pointers are device pointers on the current device; `stream` is a
  * hipStream_t (NULL = default stream).  Calls are asynchronous on `stream`
  * unless stated otherwise.
+ *
+ * Alignment: d_ws on 256 bytes, d_comp_off on 8, histograms passed to
+ * hfz_build_codes_dev on 16, every other u32/i32 array on 4 (hipMalloc and
+ * torch allocations satisfy all of these); a misaligned pointer is refused
+ * with HFZ_E_ARG.  d_raw and d_comp may have any alignment.
  */
 size_t hfz_batch_frames(size_t total, size_t frame_bytes);
 size_t hfz_workspace_bytes(int K, size_t n_frames);
@@ -199,7 +204,8 @@ int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes
                                     size_t n_frames, void* d_raw, size_t raw_cap,
                                     size_t frame_bytes, int32_t* d_status, void* stream);
 
-/* 256 byte counts (u32, wraps at 2^32) of a device buffer into d_hist[256]. */
+/* 256 byte counts (u32, wraps at 2^32) of a device buffer of any size into
+ * d_hist[256] (buffers beyond 1 GiB are counted in pieces on the same stream). */
 int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream);
 
 /* Per-frame histograms: d_hist[i*256 + c] for the batch's frames. */
@@ -217,7 +223,8 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
  * so a benchmark samples (n = 4) rather than timing every call.
  * hfz_timing_read waits for the events, returns the mean milliseconds per call
  * of each kernel over the calls recorded since the previous read, and starts a
- * new window.  Has no counterpart in the reference.
+ * new window.  hfz_timing_enable(0) also destroys the events.  Has no
+ * counterpart in the reference.
  */
 typedef struct hfz_batch_timing {
   float hist_ms;    /* input pass: per-stream byte counts (or the plain histogram, K1) */
@@ -228,6 +235,8 @@ typedef struct hfz_batch_timing {
   float decode_ms;  /* table build + decode (K4+K5) */
   int32_t compress_calls;   /* calls averaged into the first five fields */
   int32_t decompress_calls; /* calls averaged into decode_ms */
+  float count_ms;           /* input pass of hfz_count_batch_dev (the two-step shared-code encoder) */
+  int32_t count_calls;      /* calls averaged into count_ms */
 } hfz_batch_timing;
 int hfz_timing_enable(int every);
 int hfz_timing_read(hfz_batch_timing* out);

@@ -186,3 +186,43 @@ def time_roundtrip(K, raw, frame_bytes, reps=1, threads=1):
     if rc != 0:
         raise RuntimeError("oracle round trip failed: %d" % rc)
     return tc.value, td.value, ct.value
+
+
+# ---- the reference's own histogram code, compiled from its sources -----------
+# oracle/_ref/libref_hist.so is built by `make -C oracle ref` (needs
+# /root/reference, so only where the reference is present); it exists to check
+# ho_histogram against MakeHistogram itself.
+
+_REF_SO = os.path.join(_HERE, "_ref", "libref_hist.so")
+REF_HIST_VARIANTS = {"MakeHistogram": 0, "Simple": 1, "Multi": 2, "Vectorized": 3,
+                     "GatherScatter": 4}
+_ref = None
+
+
+def ref_available():
+    """True when the compiled reference histogram exists and this CPU can run it
+    (the reference's histogram.cpp is built with the AVX-512 subsets it uses)."""
+    if not os.path.exists(_REF_SO):
+        return False
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = f.read()
+    except OSError:
+        return False
+    return all(x in flags for x in ("avx512f", "avx512bw", "avx512dq", "avx512vl", "bmi2"))
+
+
+def ref_histogram(raw, variant="MakeHistogram"):
+    """huffman::MakeHistogram* of the reference (codec/histogram.cpp) on `raw`."""
+    global _ref
+    if _ref is None:
+        L = ctypes.CDLL(_REF_SO)
+        L.ref_histogram.restype = ctypes.c_int
+        L.ref_histogram.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        _ref = L
+    p, n, keep = _buf(raw)
+    h = np.zeros(256, dtype=np.uint32)
+    rc = _ref.ref_histogram(REF_HIST_VARIANTS[variant], p, n, h.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ref_histogram failed")
+    return h

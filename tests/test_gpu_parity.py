@@ -142,6 +142,7 @@ def test_generator_matches_oracle(torch_cuda):
 
 @pytest.mark.parametrize("K,total,frame_bytes,strided", [
     (64, 1 << 20, 64 << 10, False),
+    (64, 8 << 20, 1 << 20, False),         # 64 streams, 1 MiB frames: one wave64 per frame, 16 KiB slices
     (64, (1 << 20) + 12345, 64 << 10, True),
     (32, 300000, 100000, False),
     (32, 1 << 20, 1 << 20, False),
@@ -253,13 +254,12 @@ def test_corrupt_frames_are_rejected_not_crashing(torch_cuda):
     assert got.value == len(raw)
 
 
-def test_full_size_round_trip_properties(torch_cuda):
-    # 256 MiB at K=64 (the single-GPU benchmark configuration): too large for
-    # the oracle, so use size-independent properties: decode(encode(x)) == x,
-    # every frame header carries its raw size, sizes sum to the packed length.
-    torch = torch_cuda
-    K, total, frame_bytes = 64, 256 << 20, 64 << 10
-    raw = hfz.generate(geometric_cdf(), 2024, total)
+def _round_trip_properties(torch, K, total, frame_bytes, source, seed, ratio_band):
+    """Batches too large for the oracle: size-independent properties (decode(encode(x))
+    == x, every frame ok, offsets = prefix sums of sizes, every header carries its
+    frame's raw size, ratio in the source's band) plus three spot frames that must
+    equal the oracle's bytes."""
+    raw = hfz.generate(hfz.distributions.SOURCES[source](), seed, total)
     codec = hfz.BatchCodec(K, total, frame_bytes)
     batch = codec.compress(raw)
     out = codec.decompress(batch)
@@ -269,15 +269,73 @@ def test_full_size_round_trip_properties(torch_cuda):
     assert torch.equal(out, raw)
     sizes = batch.comp_size.to(torch.int64)
     offs = batch.comp_off
+    assert int(offs[0].item()) == 0
     assert torch.equal(offs[1:], torch.cumsum(sizes, 0)[:-1])
+    # header word 0 of every frame = its raw size
+    idx = offs.unsqueeze(1) + torch.arange(4, device=offs.device).unsqueeze(0)
+    hdr = batch.comp[idx.reshape(-1)].reshape(-1, 4).to(torch.int64)
+    raw_sizes = hdr[:, 0] | (hdr[:, 1] << 8) | (hdr[:, 2] << 16) | (hdr[:, 3] << 24)
+    want_sizes = torch.full((codec.n_frames,), frame_bytes, dtype=torch.int64, device=offs.device)
+    want_sizes[-1] = total - (codec.n_frames - 1) * frame_bytes
+    assert torch.equal(raw_sizes, want_sizes)
     ratio = float(sizes.sum().item()) / total
-    assert 0.44 < ratio < 0.48  # order-0 entropy of P(i)=0.8^i*0.2 is 3.61 bits
-    # spot-check three frames against the oracle
-    host_comp = batch.comp
+    assert ratio_band[0] < ratio < ratio_band[1], ratio
     for i in (0, codec.n_frames // 2, codec.n_frames - 1):
         chunk = raw[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().tobytes()
-        o, s = int(offs[i].item()), int(sizes[i].item())
-        assert host_comp[o:o + s].cpu().numpy().tobytes() == oracle.compress(K, chunk)
+        o, sz = int(offs[i].item()), int(sizes[i].item())
+        assert batch.comp[o:o + sz].cpu().numpy().tobytes() == oracle.compress(K, chunk), i
+    return codec
+
+
+@pytest.mark.parametrize("frame_kib", [64, 128])
+def test_full_size_round_trip_properties(torch_cuda, frame_kib):
+    # 256 MiB at K=64, the single-GPU benchmark configuration (128 KiB frames is the
+    # benchmark's default line).  Order-0 entropy of P(i)=0.8^i*0.2 is 3.61 bits.
+    _round_trip_properties(torch_cuda, 64, 256 << 20, frame_kib << 10, "biased", 2024, (0.44, 0.48))
+
+
+def test_one_mib_frames_at_scale(torch_cuda):
+    # 64 streams, 1 MiB frames, 2 GiB + a ragged last frame: enough frames (2049) that
+    # the launcher picks what it picks on a full GPU's share of such a job: packed
+    # 16-bit counters in the counting kernel, 64-byte encoder blocks, the 11-bit
+    # decode table with paired 64-byte stores
+    codec = _round_trip_properties(torch_cuda, 64, (2 << 30) + 300000, 1 << 20, "biased", 77,
+                                   (0.44, 0.48))
+    assert codec.n_frames == 2049
+
+
+def test_32_streams_text_like_at_scale(torch_cuda):
+    # the 32-stream format on 1 GiB of wiki-text-like data in 512 KiB frames: 2048
+    # frames, so two frames share a wave in the encoder and the decoder without
+    # being forced to (order-0 entropy of the table is 5.1 bits/byte)
+    codec = _round_trip_properties(torch_cuda, 32, 1 << 30, 512 << 10, "enwik", 4242, (0.63, 0.67))
+    assert codec.n_frames == 2048
+
+
+def test_histogram_of_more_than_4_gib(torch_cuda):
+    # hfz_histogram_dev counts a large buffer in pieces; checked against torch.bincount
+    torch = torch_cuda
+    n = (4 << 30) + (1 << 30) + 12345
+    raw = hfz.generate(geometric_cdf(), 9, n)
+    d_h = torch.zeros(256, dtype=torch.int32, device="cuda")
+    rc = hfz.lib().hfz_histogram_dev(raw.data_ptr(), n, d_h.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = d_h.cpu().numpy().view(np.uint32).astype(np.uint64)
+    want = torch.zeros(256, dtype=torch.int64, device="cuda")
+    step = 256 << 20
+    for lo in range(0, n, step):
+        want += torch.bincount(raw[lo:lo + step].to(torch.int32), minlength=256)
+    want = want.cpu().numpy().astype(np.uint64)
+    assert int(want.sum()) == n
+    assert np.array_equal(got, want & np.uint64(0xffffffff))
+    assert np.array_equal(hfz.histogram_dev(raw), want)
+    # misaligned pointers are refused, not passed to vector loads
+    assert hfz.lib().hfz_histogram_dev(raw.data_ptr(), 1000, d_h.data_ptr() + 2, None) == hfz.HFZ_E_ARG
+    h16 = torch.zeros(512, dtype=torch.int32, device="cuda")
+    codes = torch.zeros(792, dtype=torch.uint8, device="cuda")
+    assert hfz.lib().hfz_build_codes_dev(h16.data_ptr() + 4, 1, codes.data_ptr(), None) == hfz.HFZ_E_ARG
 
 
 # ---- device-side canonical code construction --------------------------------
@@ -546,6 +604,17 @@ def test_command_line_tool_round_trip(torch_cuda, tmp_path):
     assert r.returncode != 0
     r = subprocess.run([tool, "t", str(packed)[:-4] + ".bin"], capture_output=True)  # not a container
     assert r.returncode != 0
+    # a frame whose header claims fewer raw bytes than the container gives it must
+    # not pass (the device alone would accept it and leave stale output bytes)
+    blob = bytearray(packed.read_bytes())
+    first = 32 + 4 * len(frames)
+    claimed = int.from_bytes(blob[first:first + 4], "little")
+    blob[first:first + 4] = (claimed - 1).to_bytes(4, "little")
+    (tmp_path / "short.hfz").write_bytes(bytes(blob))
+    for mode in (["t", str(tmp_path / "short.hfz")],
+                 ["d", str(tmp_path / "short.hfz"), str(tmp_path / "short.out")]):
+        r = subprocess.run([tool] + mode, capture_output=True)
+        assert r.returncode != 0 and b"raw size" in r.stderr, (mode, r.stderr)
 
 
 # ---- randomized sweep ----------------------------------------------------------

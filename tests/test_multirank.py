@@ -92,9 +92,114 @@ def _shared_code_worker(rank, world, port, tmpdir):
         big = np.zeros(256, dtype=np.uint64)
         big[0], big[1], big[2] = 1 << 40, 3, 0
         s = hfz.scale_histogram(big)
-        assert s[0] == 1 << 31 and s[1] == 1 and s[2] == 0
+        assert s[0] == 1 << 30 and s[1] == 1 and s[2] == 0
         open(os.path.join(tmpdir, "ok2"), "w").write("ok")
     dist.destroy_process_group()
+
+
+def _bench_bookkeeping_worker(rank, world, port, tmpdir):
+    # bench.py's own job functions (barrier, slowest rank's time, the shared-table
+    # exchange, whole-job throughput) under gloo: the N > 1 branches the benchmark
+    # runs on the GPUs, executed here on CPU tensors
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bench
+    import oracle
+    hfz = importlib.import_module("huffman-avx512_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.01 * (rank + 1))  # rank 1 is the slow one
+        return len(calls)
+
+    steps, warmup = 5, 2
+    elapsed, last = bench.time_steps(step, steps, warmup, world, False, cpu)
+    assert last == steps + warmup and len(calls) == steps + warmup  # exactly K timed steps
+    assert elapsed >= steps * 0.01 * world * 0.95                     # the slowest rank's time
+    both = [None] * world
+    dist.all_gather_object(both, elapsed)
+    assert both[0] == both[1]                                         # the same number on every rank
+    assert bench.job_value(world, 256.0, 2.0, 4) == world * 256.0 / 0.5
+    assert bench.max_over_ranks(float(rank), world, cpu) == float(world - 1)
+
+    # the shared-table exchange: per-rank counts, one of them beyond 32 bits
+    h = torch.zeros(256, dtype=torch.int64)
+    h[rank] = (1 << 33) + 5 * rank
+    h[7] = 3
+    h[200 + rank] = 1
+    want_sum = np.zeros(256, dtype=np.uint64)
+    for r in range(world):
+        want_sum[r] += (1 << 33) + 5 * r
+        want_sum[7] += 3
+        want_sum[200 + r] += 1
+    h32 = bench.job_histogram(hfz, h, world)
+    got = h32.numpy().view(np.uint32)
+    want = hfz.scale_histogram(want_sum)
+    assert got.tolist() == want.tolist()
+    assert int(want.astype(np.uint64).sum()) < (1 << 32) and want[7] >= 1 and want[201] == 1
+    assert h[rank] == (1 << 33) + 5 * rank                            # the caller's tensor is untouched
+    # every rank builds the same code from it (host builder here, device builder on the GPUs)
+    rec = bytes(hfz.frame_code(got))
+    recs = [None] * world
+    dist.all_gather_object(recs, rec)
+    assert recs[0] == recs[1]
+    coding = oracle.make_coding(got)
+    assert bytes(hfz.frame_code(got).hdr)[4 + bin(coding.len_mask).count("1"):][:coding.num_syms] == \
+        coding.sorted_syms.tobytes()
+    if rank == 0:
+        open(os.path.join(tmpdir, "ok3"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_two_ranks_bench_bookkeeping(tmp_path):
+    import torch.multiprocessing as mp
+    port = 30700 + (os.getpid() % 500)
+    mp.spawn(_bench_bookkeeping_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok3").exists()
+
+
+def test_scale_histogram_keeps_sums_below_32_bits():
+    # the code builders add node counts in 32 bits (as codec/huffman.cpp:364-416
+    # does): after scaling, the Huffman code they build must be a true Huffman code
+    # of the scaled counts, i.e. cost what a 64-bit construction costs
+    import heapq
+    import numpy as np
+    hfz = importlib.import_module("huffman-avx512_amd")
+    rng = np.random.default_rng(7)
+    for case in range(20):
+        nsym = int(rng.integers(2, 60))
+        h = np.zeros(256, dtype=np.uint64)
+        idx = rng.choice(256, size=nsym, replace=False)
+        h[idx] = rng.integers(1, 1 << 36, size=nsym).astype(np.uint64)  # sums far beyond 2^32
+        s = hfz.scale_histogram(h)
+        assert int(s.astype(np.uint64).sum()) < (1 << 32)
+        assert ((s > 0) == (h > 0)).all()
+        import torch
+        assert hfz.scale_histogram_dev(torch.from_numpy(h.astype(np.int64))).numpy().view(
+            np.uint32).tolist() == s.tolist()
+        t = hfz.build_code_table(s)
+        lens = np.array(list(t.len), dtype=np.int64)
+        cost = int((s.astype(np.int64) * lens).sum())
+        heap = [int(c) for c in s if c]
+        heapq.heapify(heap)
+        best = 0
+        while len(heap) > 1:
+            a, b = heapq.heappop(heap), heapq.heappop(heap)
+            best += a + b
+            heapq.heappush(heap, a + b)
+        if lens.max() < 12:  # no length limiting happened: the code is optimal
+            assert cost == best, case
+        else:
+            assert cost >= best
 
 
 def test_two_ranks_shared_code(tmp_path):

@@ -56,6 +56,18 @@ KERNEL(k_lds_rd2, "ds_read2_b32 %4, %0 offset1:1\n", "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_mix_valu_lds, "ds_read_b32 %1, %6\n v_add_u32 %3, %0, %2\n v_add_u32 %3, %0, %2\n", "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_mix_valu_salu, "v_add_u32 %3, %0, %2\n s_add_u32 s20, s20, 1\n", "")
 KERNEL(k_mix_wait, "v_add_u32 %3, %0, %2\n s_waitcnt lgkmcnt(0)\n", "")
+KERNEL(k_lshr32_e32, "v_lshrrev_b32_e32 %1, 3, %1\n", "")
+KERNEL(k_and_lit, "v_and_b32_e32 %1, 0x1ffc, %1\n", "")
+KERNEL(k_alignbit, "v_alignbit_b32 %1, %1, %0, %2\n", "")
+KERNEL(k_perm, "v_perm_b32 %1, %1, %0, %2\n", "")
+KERNEL(k_lshr64, "v_lshrrev_b64 %4, %2, %4\n", "")
+KERNEL(k_lds_wr16_rand, "ds_write_b16 %6, %1\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_lds_wr16hi_rand, "ds_write_b16_d16_hi %6, %1\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_lds_wr8_rand, "ds_write_b8 %6, %1\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_lds_wr64_lin, "ds_write_b64 %0, %4\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_lds_rd_u16_rand, "ds_read_u16 %1, %6\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_lds_rd64_rand, "ds_read_b64 %4, %6\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_mix_rd_wr, "ds_read_b32 %1, %6\n ds_write_b16 %6, %2\n", "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_saveexec, "v_cmp_gt_i32 vcc, 0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n", "")
 
 typedef void (*kern_t)(uint32_t*, int);
@@ -80,7 +92,13 @@ int main(int argc, char** argv) {
       {"ds_read_b64 linear", k_lds_rd64, 1}, {"ds_read2_b32 linear", k_lds_rd2, 1},
       {"mix: 1 ds_read random + 2 v_add", k_mix_valu_lds, 1},
       {"mix: v_add + s_add", k_mix_valu_salu, 1}, {"mix: v_add + s_waitcnt", k_mix_wait, 1},
-      {"v_cmp + s_and_saveexec + s_or exec", k_saveexec, 1}};
+      {"v_cmp + s_and_saveexec + s_or exec", k_saveexec, 1},
+      {"v_lshrrev_b32_e32", k_lshr32_e32, 1}, {"v_and_b32_e32 literal", k_and_lit, 1},
+      {"v_alignbit_b32", k_alignbit, 1}, {"v_perm_b32", k_perm, 1}, {"v_lshrrev_b64 dep", k_lshr64, 1},
+      {"ds_write_b16 random", k_lds_wr16_rand, 1}, {"ds_write_b16_d16_hi random", k_lds_wr16hi_rand, 1},
+      {"ds_write_b8 random", k_lds_wr8_rand, 1}, {"ds_write_b64 linear", k_lds_wr64_lin, 1},
+      {"ds_read_u16 random", k_lds_rd_u16_rand, 1}, {"ds_read_b64 random", k_lds_rd64_rand, 1},
+      {"mix: ds_read_b32 + ds_write_b16 random", k_mix_rd_wr, 1}};
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);

@@ -47,6 +47,9 @@ void run(int blocks, int iters) {
   int max_simd = 0, max_cu = 0;
   for (auto& kv : per_simd) max_simd = kv.second > max_simd ? kv.second : max_simd;
   for (auto& kv : per_cu) max_cu = kv.second > max_cu ? kv.second : max_cu;
+  int dist[9] = {0};
+  for (auto& kv : per_simd) dist[kv.second > 8 ? 8 : kv.second]++;
+  printf("   SIMDs holding 1..8 waves: %d %d %d %d %d %d %d %d (of %zu seen)\n", dist[1], dist[2], dist[3], dist[4], dist[5], dist[6], dist[7], dist[8], per_simd.size());
   printf("lds %6d threads %3d blocks %5d: %.3f ms  distinct CUs %zu (max %d waves)  distinct SIMDs %zu (max %d waves)  simd hist %d %d %d %d  sample hwid %08x %08x %08x\n",
          LDS_BYTES, THREADS, blocks, ms, per_cu.size(), max_cu, per_simd.size(), max_simd,
          simd_hist[0], simd_hist[1], simd_hist[2], simd_hist[3], h[0], h[1], h[waves - 1]);
@@ -55,6 +58,9 @@ void run(int blocks, int iters) {
 }
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+  run<20480, 64>(1024, iters);
+  run<20480, 64>(2048, iters);
+  run<20480, 64>(1536, iters);
   run<29696, 64>(1024, iters);
   run<29696, 64>(2048, iters);
   run<29696, 64>(4096, iters);
