@@ -39,6 +39,7 @@ EXPORTS = (
     "hfz_frame_code_from_table", "hfz_build_codes_dev", "hfz_set_decoder_table_bits",
     "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
     "hfz_count_batch_dev", "hfz_compress_batch_counted_dev", "hfz_set_encoder_block",
+    "hfz_static_workspace_init", "hfz_static_max_frames", "hfz_compress_batch_static_dev",
 )
 
 
@@ -123,6 +124,12 @@ def lib():
         L.hfz_count_batch_dev.argtypes = [ci, vp, sz, sz, vp, sz, vp, vp]
         L.hfz_compress_batch_counted_dev.restype = ci
         L.hfz_compress_batch_counted_dev.argtypes = [ci, vp, sz, sz, vp, vp, sz, sz, vp, vp, vp, vp, sz, vp]
+        L.hfz_static_workspace_init.restype = ci
+        L.hfz_static_workspace_init.argtypes = []
+        L.hfz_static_max_frames.restype = sz
+        L.hfz_static_max_frames.argtypes = []
+        L.hfz_compress_batch_static_dev.restype = ci
+        L.hfz_compress_batch_static_dev.argtypes = [ci, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp]
         L.hfz_histogram_dev.restype = ci
         L.hfz_histogram_dev.argtypes = [vp, sz, vp, vp]
         L.hfz_histogram_batch_dev.restype = ci

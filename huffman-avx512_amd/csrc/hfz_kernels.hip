@@ -2065,6 +2065,72 @@ int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The batch encoder without a caller-provided workspace and without any
+// allocation: for callers that must not allocate (code under HIP graph capture,
+// tight serving loops).  The workspace (histograms, codes, stream ends, frame
+// sizes, per-stream counters) lives in a device array of this code object,
+// sized for kStaticMaxFrames frames; every GPU the library runs on holds its own
+// copy, at its own address, until the process ends.
+constexpr size_t kStaticMaxFrames = HFZ_STATIC_MAX_FRAMES;
+constexpr size_t kStaticBytes =
+    ((kStaticMaxFrames * (256 * 4 + sizeof(FrameCode) + 64 * 4 + 4 + 256 * 32 * 4)) + 5 * 256 + 255) &
+    ~size_t(255);
+static __device__ __align__(256) uint8_t scratch[kStaticBytes];
+
+namespace {
+// `scratch` in host code is only a handle for the runtime, not a device
+// address; the address on each device comes from hipGetSymbolAddress, once per
+// device, and is what the kernels get.
+constexpr int kMaxDevices = 64;
+std::atomic<uint8_t*> g_scratch_ptr[kMaxDevices];
+
+int static_workspace(uint8_t** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_failure((int)e);
+  if (dev < 0 || dev >= kMaxDevices) return HFZ_E_ARG;
+  uint8_t* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* sym = nullptr;
+    e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));  // the current device's copy
+    if (e != hipSuccess) return hip_failure((int)e);
+    if (!sym || ((uintptr_t)sym & 255) != 0) return HFZ_E_HIP;
+    p = (uint8_t*)sym;
+    g_scratch_ptr[dev].store(p, std::memory_order_release);  // racing threads store the same value
+  }
+  *out = p;
+  return HFZ_OK;
+}
+}  // namespace
+
+extern "C" int hfz_static_workspace_init(void) {
+  uint8_t* p = nullptr;
+  return static_workspace(&p);
+}
+
+extern "C" size_t hfz_static_max_frames(void) { return kStaticMaxFrames; }
+
+extern "C" int hfz_compress_batch_static_dev(int K, const void* d_raw, size_t total,
+                                             size_t frame_bytes, void* d_comp, size_t comp_cap,
+                                             size_t comp_stride, uint64_t* d_comp_off,
+                                             uint32_t* d_comp_size, int32_t* d_status,
+                                             void* stream) {
+  if (frame_bytes == 0) return HFZ_E_ARG;
+  const size_t nf = total == 0 ? 1 : (total + frame_bytes - 1) / frame_bytes;
+  if (nf > kStaticMaxFrames) return HFZ_E_TOO_LARGE;  // more frames than the static workspace holds
+  static_assert(kStaticBytes >= 256, "workspace");
+  if (workspace_layout(nf).total > kStaticBytes) return HFZ_E_TOO_LARGE;
+  uint8_t* ws = nullptr;
+  const int rc = static_workspace(&ws);
+  if (rc != HFZ_OK) return rc;
+  // Every workspace word a kernel reads in this call is written earlier in the
+  // same call (the separate-pass histogram clears its own counters with a
+  // memset on the stream), so nothing left by the previous call is looked at.
+  return compress_batch(K, d_raw, total, frame_bytes, d_comp, comp_cap, comp_stride, d_comp_off,
+                        d_comp_size, d_status, ws, kStaticBytes, nullptr, stream);
+}
+
 #ifdef HFZ_STAMP
 extern "C" int hfz_debug_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);

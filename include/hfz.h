@@ -204,6 +204,29 @@ int hfz_decompress_batch_shared_dev(int K, const void* d_comp, size_t comp_bytes
                                     size_t n_frames, void* d_raw, size_t raw_cap,
                                     size_t frame_bytes, int32_t* d_status, void* stream);
 
+/*
+ * hfz_compress_batch_dev without a workspace argument and without any allocation.
+ * No counterpart in the reference; it exists for callers that cannot allocate:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The workspace is a device array inside the library, sized for at
+ * most HFZ_STATIC_MAX_FRAMES frames per call (about 35 KiB per frame, 9 MiB per
+ * GPU, held by every GPU the library runs on until the process ends); a batch of
+ * more frames is refused with HFZ_E_TOO_LARGE.  The call makes no hipMalloc,
+ * hipFree or other allocating call as long as kernel timing (hfz_timing_enable)
+ * is off.  Output is identical to hfz_compress_batch_dev's.  All calls on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (different
+ * streams or threads) race; serialise them.  hfz_static_workspace_init resolves
+ * the array's address on the current device (the entry point does the same on
+ * its first call on a device); call it once per device before a graph capture.
+ */
+#define HFZ_STATIC_MAX_FRAMES 256
+int hfz_static_workspace_init(void);
+size_t hfz_static_max_frames(void);
+int hfz_compress_batch_static_dev(int K, const void* d_raw, size_t total, size_t frame_bytes,
+                                  void* d_comp, size_t comp_cap, size_t comp_stride,
+                                  uint64_t* d_comp_off, uint32_t* d_comp_size, int32_t* d_status,
+                                  void* stream);
+
 /* 256 byte counts (u32, wraps at 2^32) of a device buffer of any size into
  * d_hist[256] (buffers beyond 1 GiB are counted in pieces on the same stream). */
 int hfz_histogram_dev(const void* d_src, size_t n, uint32_t* d_hist, void* stream);
