@@ -40,6 +40,7 @@ EXPORTS = (
     "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
     "hfz_count_batch_dev", "hfz_compress_batch_counted_dev", "hfz_set_encoder_block",
     "hfz_static_workspace_init", "hfz_static_max_frames", "hfz_compress_batch_static_dev",
+    "hfz_set_decoder_store",
 )
 
 
@@ -148,6 +149,8 @@ def lib():
         L.hfz_set_frames_per_wave.argtypes = [ci]
         L.hfz_set_decoder_table_bits.restype = ci
         L.hfz_set_decoder_table_bits.argtypes = [ci]
+        L.hfz_set_decoder_store.restype = ci
+        L.hfz_set_decoder_store.argtypes = [ci]
         L.hfz_timing_read.restype = ci
         L.hfz_timing_read.argtypes = [ctypes.POINTER(BatchTiming)]
         _lib = L
@@ -428,6 +431,11 @@ def shard_frames(n_frames, rank, world):
 def set_decoder_table_bits(bits=0):
     """0 = automatic, 11 or 12 = force that build of the decoder's lookup table."""
     _check(lib().hfz_set_decoder_table_bits(int(bits)), "hfz_set_decoder_table_bits")
+
+
+def set_decoder_store(mode=0):
+    """0 = automatic, 1 = every lane stores its own blocks, 2 = lane pairs store together."""
+    _check(lib().hfz_set_decoder_store(int(mode)), "hfz_set_decoder_store")
 
 
 def set_frames_per_wave(n=0):

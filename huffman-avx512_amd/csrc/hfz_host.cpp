@@ -506,6 +506,12 @@ int hfz_set_encoder_block(int bytes) {
   return HFZ_OK;
 }
 
+int hfz_set_decoder_store(int mode) {
+  if (mode < 0 || mode > 2) return HFZ_E_ARG;
+  g_decoder_store = mode;
+  return HFZ_OK;
+}
+
 int hfz_timing_enable(int every) {
   if (every < 0) return HFZ_E_ARG;
   g_timing.every = every;

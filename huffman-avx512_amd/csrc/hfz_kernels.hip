@@ -1306,17 +1306,29 @@ __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) 
 // kF = 2 (K <= 32, kWaves = 1): lanes 0..31 decode frame 2b, lanes 32..63 frame
 // 2b+1 of workgroup b.  The prologue (header, table) runs once per frame with
 // all 64 lanes helping; the lanes of the frame's half keep its parameters.
-// kPair64: finished 32-byte output blocks wait in registers for their neighbour
-// and leave as one aligned 64-byte store where they can (large batches: fewer,
-// larger pieces of a line reach memory; 7-8 % faster at 1 GiB and beyond with
-// one frame per wave, slower with two).
-template <uint32_t kDecTabBits, uint32_t kWaves, uint32_t kF, bool kPair64>
+// kStore: how finished 32-byte output blocks leave the ring.
+//   0: the lane that decoded a block stores it (two 16-byte stores).
+//   1: as 0, but a block waits in registers for its neighbour and the two leave
+//      as one aligned 64-byte piece where they can (batches beyond the last-level
+//      cache: fewer, larger pieces of a line reach memory; 7-8 % faster at 1 GiB
+//      and beyond with one frame per wave, slower with two).
+//   2: lanes 2i and 2i+1 store each other's blocks together, 16 bytes each side
+//      by side, so that one store instruction writes 32 contiguous bytes of a
+//      line instead of 16 (one frame per wave only).  A store instruction whose
+//      64 lanes write 16 bytes of 64 different lines costs the memory pipeline
+//      most; this halves the number of such pieces.  11-14 % faster with slices
+//      of up to 2 KiB (128 KiB frames of 64 streams), 4-11 % slower with longer
+//      ones, where a line reaches memory in four pieces that are rounds apart
+//      instead of two and the lanes' lines crowd the same memory channels.
+template <uint32_t kDecTabBits, uint32_t kWaves, uint32_t kF, uint32_t kStore>
 __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint64_t n_frames, uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
     int32_t* __restrict__ status) {
   static_assert(kF == 1 || (kF == 2 && kWaves == 1), "two frames per wave only without table sharing");
+  static_assert(kStore <= 2 && (kStore != 2 || (kF == 1 && kWaves == 1)), "pair stores: one frame per wave");
+  constexpr bool kPair64 = kStore == 1;
   __shared__ uint32_t tab[kF << kDecTabBits];
   __shared__ uint32_t ringmem[kWaves * 64 * (kDecInDw + kDecOutDw)];
   const uint32_t tid = threadIdx.x;
@@ -1716,6 +1728,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     can = left > 0;
     STAMP(3);  // staging
     while (__any(can)) {
+      const bool ran = can;
       if (can) {
         if (left >= 2 * kDecRound) {
           // fast round: every lookup may emit two symbols without bounds checks
@@ -1758,7 +1771,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           wp += (wa - wa_b) >> 6;
         }
         // last round's block goes to memory, the one this round filled is read
-        if (!kPair64) {
+        if (kStore == 2) {
+          // handled after the round, by all lanes (below)
+        } else if (!kPair64) {
           if (sb_full) HFZ_STORE_BLOCK();
           sb_full = wp >= nfb + kDecBlk;
           if (sb_full) HFZ_TAKE_BLOCK();
@@ -1793,10 +1808,45 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         }
         can = left > 0 && ip - kReach >= low_blk;
       }
+      if (kStore == 2) {
+        // A round adds at most 32 bytes, so at most one more block is complete.
+        // A lane that completed one tells its neighbour where it goes; the two
+        // lanes fetch one 16-byte half each from the owner's ring rows and store
+        // them side by side.  First and last block of a slice (they may hold a
+        // neighbour's bytes) are stored by their owner alone, byte-clipped.
+        const bool full = ran && wp >= nfb + kDecBlk;
+        if (__ballot(full)) {
+          wave_sync();  // ring rows written in the round are read by the neighbour lane
+          const bool whole = nfb >= out_lo && nfb + kDecBlk <= out_hi;
+          if (full && !whole) {
+            HFZ_TAKE_BLOCK();  // advances nfb
+            HFZ_STORE_BLOCK();
+          }
+          // (nfb | 1) if this lane hands a block over, else 0 (nfb is a multiple of 32)
+          const uint32_t give = full && whole ? nfb | 1u : 0u;
+          if (full && whole) nfb += kDecBlk;
+          // what the even and the odd lane of the pair hand over: quad_perm [0,0,2,2] / [1,1,3,3]
+          const uint32_t g_even = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xA0, 0xf, 0xf, false);
+          const uint32_t g_odd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xF5, 0xf, 0xf, false);
+          const uint32_t half16 = lane & 1;  // which 16 bytes of the 32 this lane moves
+          const uint32_t* const pair_rows = obuf_all + (lane & ~1u) + 64 * 4 * half16;
+          uint4 v_even, v_odd;
+          if (g_even) {
+            const uint32_t* src = pair_rows + 64 * ((g_even & kDecBlk) >> 2);
+            v_even = make_uint4(src[0], src[64], src[128], src[192]);
+          }
+          if (g_odd) {
+            const uint32_t* src = pair_rows + 1 + 64 * ((g_odd & kDecBlk) >> 2);
+            v_odd = make_uint4(src[0], src[64], src[128], src[192]);
+          }
+          if (g_even) *(uint4*)(obase + (g_even & ~1u) + 16 * half16) = v_even;
+          if (g_odd) *(uint4*)(obase + (g_odd & ~1u) + 16 * half16) = v_odd;
+        }
+      }
     }
     STAMP(4);  // rounds
   }
-  if (sb_full) HFZ_STORE_BLOCK();
+  if (kStore != 2 && sb_full) HFZ_STORE_BLOCK();
   if (kPair64 && sc_full) HFZ_STORE_ODD_BLOCK();
   // the last partial dword, then what is left in the ring: up to two blocks
   *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;
@@ -1882,6 +1932,7 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 std::atomic<int> g_decoder_table_bits{0};
 std::atomic<int> g_frames_per_wave{0};
 std::atomic<int> g_encoder_block{0};
+std::atomic<int> g_decoder_store{0};
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -2010,6 +2061,10 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
 }
 
 constexpr uint32_t kSharedWaves = 3;  // frames per workgroup when they share one code
+// Lane pairs store together while the streams of a frame lie at most this far
+// apart (measured with 64 streams: 128 KiB frames 11-14 % faster that way from
+// 128 MiB to 4 GiB, 256 KiB frames and larger 4-11 % slower).
+constexpr uint64_t kPairStoreMaxSlice = 2048;
 constexpr uint64_t kSharedMaxFrame = 128u << 10;
 
 
@@ -2025,7 +2080,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     // frames go through the per-frame kernels below, which are faster there
     // (one-wave workgroups pack the CUs better) and decode any frame.
     const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
-    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves, 1, false>), dim3((uint32_t)groups),
+    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves, 1, 0>), dim3((uint32_t)groups),
                        dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
                        comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
                        d_status);
@@ -2038,18 +2093,24 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
-    hipLaunchKernelGGL((decode_kernel<11, 1, 2, false>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
+    hipLaunchKernelGGL((decode_kernel<11, 1, 2, 0>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
     return hipGetLastError();
   }
   const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
-    hipLaunchKernelGGL((decode_kernel<12, 1, 1, false>), dim3((uint32_t)n_frames), dim3(64), 0,
+    hipLaunchKernelGGL((decode_kernel<12, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
+                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+  else if (g_decoder_store.load(std::memory_order_relaxed)
+               ? g_decoder_store.load(std::memory_order_relaxed) == 2
+               : frame_bytes <= kPairStoreMaxSlice * (uint64_t)K)
+    hipLaunchKernelGGL((decode_kernel<11, 1, 1, 2>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   else
-    hipLaunchKernelGGL((decode_kernel<11, 1, 1, true>), dim3((uint32_t)n_frames), dim3(64), 0,
+    hipLaunchKernelGGL((decode_kernel<11, 1, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   return hipGetLastError();

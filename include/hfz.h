@@ -291,6 +291,16 @@ int hfz_set_frames_per_wave(int n);
 int hfz_set_encoder_block(int bytes);
 
 /*
+ * How the one-frame-per-wave decoder with the 11-bit table writes its output:
+ * mode = 1, every lane stores the blocks of its own stream, two 32-byte blocks
+ * at a time (best for long streams); mode = 2, neighbouring lanes store each
+ * other's 32-byte blocks together, 16 bytes each (best for streams of up to
+ * 2 KiB, e.g. 128 KiB frames of 64 streams); 0 (default) picks by frame size.  Decoded bytes are identical.  Process-wide; no counterpart in the
+ * reference.
+ */
+int hfz_set_decoder_store(int mode);
+
+/*
  * Deterministic integer-only synthetic source, filled on the device:
  * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
  * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).

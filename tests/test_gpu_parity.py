@@ -82,6 +82,34 @@ def test_both_decoder_table_builds(torch_cuda, bits):
         hfz.set_decoder_table_bits(0)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_decoder_store_modes(torch_cuda, mode):
+    # the 11-bit one-frame-per-wave decoder writes its output in one of two ways,
+    # chosen by batch size; force each one over every reference case and a batch
+    torch = torch_cuda
+    hfz.set_decoder_table_bits(11)
+    hfz.set_decoder_store(mode)
+    try:
+        for name in CASE_FILES:
+            raw = load_input(name)
+            for K in KS:
+                assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (mode, name, K)
+        for i, raw in enumerate(many_random()):
+            for K in (1, 7, 32, 64):
+                assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (mode, i, K)
+        for K, total, frame in ((64, (6 << 20) + 77, 64 << 10), (48, 1000003, 30011), (33, 5000, 100),
+                                (64, 300, 7)):
+            data = hfz.generate(geometric_cdf(), 5 + K, total)
+            codec = hfz.BatchCodec(K, total, frame)
+            out = codec.decompress(codec.compress(data))
+            torch.cuda.synchronize()
+            assert int(codec.dstatus.abs().sum().item()) == 0, (mode, K)
+            assert torch.equal(out, data), (mode, K)
+    finally:
+        hfz.set_decoder_table_bits(0)
+        hfz.set_decoder_store(0)
+
+
 def test_encoder_block_sizes(torch_cuda):
     # the encoder picks 32- or 64-byte output blocks by frame count; force each one
     # over every reference case
@@ -637,6 +665,7 @@ def test_random_batches_equal_oracle(torch_cuda):
             src = sources[int(rng.integers(0, len(sources)))]
             strided = bool(rng.integers(0, 2))
             hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12])))
+            hfz.set_decoder_store(int(rng.choice([0, 1, 2])))
             hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
             hfz.set_encoder_block(int(rng.choice([0, 32, 64])))
             raw = hfz.generate(src, 1000 + case, total) if total else torch.empty(
@@ -655,5 +684,6 @@ def test_random_batches_equal_oracle(torch_cuda):
                     K, host[i * frame_bytes:(i + 1) * frame_bytes]), tag + (i,)
     finally:
         hfz.set_decoder_table_bits(0)
+        hfz.set_decoder_store(0)
         hfz.set_frames_per_wave(0)
         hfz.set_encoder_block(0)
