@@ -28,6 +28,7 @@ HFZ_E_TOO_LARGE = -6
 HFZ_E_WORKSPACE = -7
 HFZ_E_CODE_MISMATCH = -8
 MAX_STREAMS = 64
+DECODER_TABLE_FREE = -1
 
 # Every symbol include/hfz.h declares.
 EXPORTS = (
@@ -429,7 +430,8 @@ def shard_frames(n_frames, rank, world):
 
 
 def set_decoder_table_bits(bits=0):
-    """0 = automatic, 11 or 12 = force that build of the decoder's lookup table."""
+    """0 = automatic, 11 or 12 = force that build of the decoder's lookup table,
+    DECODER_TABLE_FREE (-1) = the table-free compare-and-index build."""
     _check(lib().hfz_set_decoder_table_bits(int(bits)), "hfz_set_decoder_table_bits")
 
 

@@ -489,7 +489,7 @@ int hfz_frame_code_from_table(const hfz_code_table* t, hfz_frame_code* out) {
 }
 
 int hfz_set_decoder_table_bits(int bits) {
-  if (bits != 0 && bits != 11 && bits != 12) return HFZ_E_ARG;
+  if (bits != 0 && bits != 11 && bits != 12 && bits != HFZ_DECODER_TABLE_FREE) return HFZ_E_ARG;
   g_decoder_table_bits = bits;
   return HFZ_OK;
 }

@@ -1298,6 +1298,27 @@ __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) 
   return (uint32_t)kMaxCodeLen | (8u << 8) | (sym << 16);
 }
 
+// Table-free build (kDecTabBits = 0): the reference's permute decoder
+// (codec/huffman.cpp:1697-1756, 1892-1940) finds a code's length by comparing
+// the window with the first code of every length and its symbol by indexing
+// the canonical symbol list, and needs no lookup table.  The same here: 13
+// words (first code and first symbol index per length) and the 256-byte symbol
+// list in LDS instead of an 8 or 16 KiB table; one symbol per step, the length
+// found by counting the lengths whose first code is not above the window's 12
+// bits (the first codes ascend with the length).  It builds the same one-symbol
+// entry a table lookup would return, so everything around it is shared.
+__device__ __forceinline__ uint32_t table_free_entry(uint64_t bitbuf, const uint32_t (&fend)[kMaxCodeLen],
+                                                     const uint32_t* cls) {
+  const uint32_t c12 = (uint32_t)(bitbuf >> 52);
+  uint32_t L = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxCodeLen; ++l) L += c12 >= fend[l] ? 1u : 0u;  // fend[l] = first code beyond length l
+  const uint32_t cl = cls[L];                                           // first code | first symbol index << 16
+  const uint32_t idx = (cl >> 16) + ((c12 - (cl & 0xffffu)) >> ((uint32_t)kMaxCodeLen - L));
+  const uint32_t sym = ((const uint8_t*)(cls + 16))[idx];
+  return L | (8u << 8) | (sym << 16);
+}
+
 // kWaves = 1: one frame per wave and workgroup, every frame builds its own table.
 // kWaves > 1 (shared-code batches): kWaves frames per workgroup, one wave each;
 // the table is built once, by all waves, from the header of the workgroup's
@@ -1329,7 +1350,13 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   static_assert(kF == 1 || (kF == 2 && kWaves == 1), "two frames per wave only without table sharing");
   static_assert(kStore <= 2 && (kStore != 2 || (kF == 1 && kWaves == 1)), "pair stores: one frame per wave");
   constexpr bool kPair64 = kStore == 1;
-  __shared__ uint32_t tab[kF << kDecTabBits];
+  constexpr bool kTableFree = kDecTabBits == 0;
+  static_assert(!kTableFree || (kF == 1 && kWaves == 1), "table-free build: one frame per wave");
+  // table-free: words 0..12 first code | first symbol index << 16 per length, bytes 64.. the symbol list
+  __shared__ uint32_t tab[kTableFree ? 16 + 64 : (kF << kDecTabBits)];
+  uint32_t fend[kMaxCodeLen];  // table-free: first code beyond every length below 12 (wave-uniform)
+#pragma unroll
+  for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = 0;
   __shared__ uint32_t ringmem[kWaves * 64 * (kDecInDw + kDecOutDw)];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -1489,9 +1516,17 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     // single-symbol entries, one code-length class at a time; table indices are
     // the top kDecTabBits bits of the left-aligned 12-bit code space
     uint32_t* const ptab = tab + (pass << kDecTabBits);
-    constexpr uint32_t kTabShift = (uint32_t)kMaxCodeLen - kDecTabBits;
+    constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
     static_assert(kTabShift <= 1, "escape entries cover one bit");
-    if (kF == 1 || p_err == HFZ_OK) {
+    if (kTableFree) {
+#pragma unroll
+      for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = __builtin_amdgcn_readfirstlane(fcode[l + 1]);
+#pragma unroll
+      for (int L = 0; L <= kMaxCodeLen; ++L)
+        if (lane == (uint32_t)L) tab[L] = fcode[L] | (soff[L] << 16);
+      uint8_t* const list = (uint8_t*)(tab + 16);
+      for (uint32_t i = lane; i < nsym; i += 64) list[i] = syms[i];
+    } else if (kF == 1 || p_err == HFZ_OK) {
 #pragma unroll
       for (uint32_t L = 0; L <= kDecTabBits; ++L) {
         if (cnt[L] == 0) continue;
@@ -1517,7 +1552,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     // second symbol where both codes fit in the index bits.  Byte 2 of an entry
     // and l1tab never change in this pass, so reading another lane's entry while
     // it is being rewritten is safe.
-    if (kF == 1 || p_err == HFZ_OK) {
+    if (!kTableFree && (kF == 1 || p_err == HFZ_OK)) {
 #pragma unroll 8
       for (uint32_t e = tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
         const uint32_t L1 = l1tab[e];
@@ -1654,8 +1689,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   } while (0)
 #define HFZ_LOOKUP()                                                         \
   do {                                                                       \
-    const uint32_t e_ = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];     \
-    if (kDecTabBits < (uint32_t)kMaxCodeLen) {                               \
+    const uint32_t e_ = kTableFree ? table_free_entry(bitbuf, fend, tab)     \
+                                   : mytab[(uint32_t)(bitbuf >> (64 - (kTableFree ? 1 : kDecTabBits)))]; \
+    if (!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen) {                \
       /* offset 24 iff escape (bit 7 of e_) and the 12th bit (bit 52) is set; \
          v_bfe_u32 looks at bits 0..4 of offset and width, and of those      \
          e_ >> 4 can only have bit 3 set (consumed < 16, 8 * count is 8 or   \
@@ -1751,8 +1787,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
           const uint32_t wa_b = wa;
           for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-            uint32_t e = mytab[(uint32_t)(bitbuf >> (64 - kDecTabBits))];
-            if (kDecTabBits < (uint32_t)kMaxCodeLen && (e & kDecEsc)) e = resolve_escape(e, bitbuf);
+            uint32_t e = kTableFree ? table_free_entry(bitbuf, fend, tab)
+                                    : mytab[(uint32_t)(bitbuf >> (64 - (kTableFree ? 1 : kDecTabBits)))];
+            if (!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen && (e & kDecEsc)) e = resolve_escape(e, bitbuf);
             uint32_t ns = (e >> 11) & 3;
             uint32_t pair = e >> 16;
             if (ns > left) {
@@ -2091,6 +2128,13 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // costs less than the extra resident waves return.
   const int cus = device_cus();
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
+  if (tab_bits == HFZ_DECODER_TABLE_FREE) {
+    // only on request (tests, comparison): one symbol per step, no lookup table
+    hipLaunchKernelGGL((decode_kernel<0, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
+                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
+                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    return hipGetLastError();
+  }
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
     hipLaunchKernelGGL((decode_kernel<11, 1, 2, 0>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,

@@ -56,10 +56,11 @@ def test_many_random(torch_cuda):
             assert hfz.decompress(K, comp) == raw, (i, K)
 
 
-@pytest.mark.parametrize("bits", [11, 12])
+@pytest.mark.parametrize("bits", [11, 12, hfz.DECODER_TABLE_FREE])
 def test_both_decoder_table_builds(torch_cuda, bits):
     # the decoder picks its lookup-table build by frame count; force each one over
-    # every reference case (12-bit codes take the escape entries of the 11-bit build)
+    # every reference case (12-bit codes take the escape entries of the 11-bit build),
+    # and the table-free build (first-code compare chain + canonical symbol list)
     torch = torch_cuda
     hfz.set_decoder_table_bits(bits)
     try:
@@ -664,7 +665,7 @@ def test_random_batches_equal_oracle(torch_cuda):
             total = max(0, frame_bytes * n_frames - int(rng.integers(0, frame_bytes)))
             src = sources[int(rng.integers(0, len(sources)))]
             strided = bool(rng.integers(0, 2))
-            hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12])))
+            hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12, hfz.DECODER_TABLE_FREE])))
             hfz.set_decoder_store(int(rng.choice([0, 1, 2])))
             hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
             hfz.set_encoder_block(int(rng.choice([0, 32, 64])))
