@@ -1249,9 +1249,9 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // (codec/huffman.cpp:644-681) is rebuilt in LDS from the frame header, then
 // lane k decodes stream k (CodeReader + Decode, codec/huffman.cpp:502-586,
 // 683-689, 931-953).  Entry layout (u32): byte 0 bits consumed, byte 1 eight
-// times the symbol count, byte 2 first symbol, byte 3 second symbol (0 if
-// none), so that consuming a code is one 64-bit shift by the entry itself and
-// appending its symbols is one shift by a running bit offset.
+// times the symbol count, byte 2 first symbol, byte 3 second symbol, so that
+// the bit position advances by adding the entry itself and appending its
+// symbols is one shift by a running bit offset.
 //
 // Every lane moves its own stream between global memory and LDS in whole,
 // aligned blocks: 64-byte input blocks (four 16-byte loads) into a two-block
@@ -1265,14 +1265,35 @@ __global__ __launch_bounds__(64) void encode_kernel(
 // kDecRound lookups (at most 24 input bytes, at most 32 output bytes, one block
 // store) until all of them have run out again.  All loads of a wave are thus
 // issued together and have a whole super-round (~70 lookups) to arrive.
+//
+// The bit reader works on bit-reversed dwords.  A stream is read from its last
+// byte downwards, most significant bit first; staging reverses the bits of every
+// dword, so in the ring the stream is a sequence of dwords (descending
+// addresses) that is consumed from bit 0 upwards.  The next code then sits at
+// the BOTTOM of a 64-bit shift of two ring dwords, where one AND turns it into
+// the byte offset of its table entry, and the table is indexed by the reversed
+// code prefix.  The reader holds the two dwords under the bit position and the
+// next one, fetched a pair of lookups ahead; after every pair it moves on by a
+// whole dword or not at all (a pair consumes at most 24 bits), which is two
+// bit-field selects and one aligned ring read.
+//
+// A lane does not stop exactly at the end of its slice: rounds always run all
+// their lookups, and the up to 31 symbols decoded past the end (from whatever
+// bits lie below the stream) stay in the output ring and are clipped away when
+// the block is stored.  The decoded bytes of the slice are the same as with an
+// exact stop (the last symbol may be the first half of a two-symbol entry,
+// Decode1, codec/huffman.cpp:875-878: the second half is clipped).
 constexpr uint32_t kDecInBlk = 64;   // bytes per staged input block
 constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
-constexpr uint32_t kDecRound = 16;   // lookups per round (four windows of four)
+constexpr uint32_t kDecRound = 16;   // lookups per round (eight pairs)
 constexpr uint32_t kDecInDw = 32;    // input ring per lane: 128 bytes
 constexpr uint32_t kDecOutDw = 16;   // output ring per lane: 64 bytes
+constexpr uint32_t kDecRoundDw = 6;  // a round consumes at most 16 * 12 bits = 6 dwords
 // Both rings are stored transposed, dword d of lane l at [d * 64 + l]: whatever
 // ring positions the lanes are at, an access puts lane l on bank l % 32, so the
-// rings never cause bank conflicts and need no padding.
+// rings never cause bank conflicts and need no padding.  The input ring holds
+// the dword at byte offset 4 * d of the stream in row 31 - (d & 31): rows grow
+// as the reader walks down the stream.
 //
 // The decoder exists in two builds.  With kDecTabBits = 11 the lookup table is
 // indexed by the next 11 bits, not 12: it is half the size
@@ -1280,23 +1301,11 @@ constexpr uint32_t kDecOutDw = 16;   // output ring per lane: 64 bytes
 // up to 11 bits, and pairs of codes of up to 11 bits together, resolve in one
 // lookup.  12-bit codes come in sibling pairs that share an 11-bit prefix (the
 // code is complete and they are the numerically last codes), so their entry
-// holds both symbols and the 12th bit picks one (kDecEsc entries).
-constexpr uint32_t kDecEsc = 0x80u;
-
-// Entry layout: byte 0 = bits consumed (bits 0..5; bit 7 = kDecEsc), byte 1 =
-// 8 * number of symbols, byte 2 = first symbol, byte 3 = second symbol (0 if
-// none).  An escape entry consumes 12 bits, counts one symbol and carries the
-// two sibling symbols in bytes 2 and 3.  Consuming a code (a 64-bit shift by
-// the entry itself, which looks at bits 0..5 only) therefore never waits for
-// the escape to be resolved; only the extraction of the symbols does: they are
-// the cnt8 bits at offset 16, or at offset 24 for the second sibling, which is
-// one v_bfe_u32 with a computed offset.  This turns an escape entry into a
-// plain one-symbol entry given the window it was looked up with (slow path).
-__device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) {
-  const uint32_t sel = (uint32_t)(bitbuf >> (63 - 11)) & 1;
-  const uint32_t sym = (e >> (16 + 8 * sel)) & 0xff;
-  return (uint32_t)kMaxCodeLen | (8u << 8) | (sym << 16);
-}
+// holds both symbols (bytes 2 and 3) and counts one; the 12th bit picks the
+// byte.  Plain one-symbol entries of this build carry their symbol in both
+// bytes, so the same pick (one v_bfe_u32 whose offset is 16, or 24 if the
+// entry counts one symbol and the 12th bit is set) serves every entry and
+// nothing has to tell the sibling entries apart.
 
 // Table-free build (kDecTabBits = 0): the reference's permute decoder
 // (codec/huffman.cpp:1697-1756, 1892-1940) finds a code's length by comparing
@@ -1307,9 +1316,8 @@ __device__ __forceinline__ uint32_t resolve_escape(uint32_t e, uint64_t bitbuf) 
 // found by counting the lengths whose first code is not above the window's 12
 // bits (the first codes ascend with the length).  It builds the same one-symbol
 // entry a table lookup would return, so everything around it is shared.
-__device__ __forceinline__ uint32_t table_free_entry(uint64_t bitbuf, const uint32_t (&fend)[kMaxCodeLen],
+__device__ __forceinline__ uint32_t table_free_entry(uint32_t c12, const uint32_t (&fend)[kMaxCodeLen],
                                                      const uint32_t* cls) {
-  const uint32_t c12 = (uint32_t)(bitbuf >> 52);
   uint32_t L = 0;
 #pragma unroll
   for (int l = 0; l < kMaxCodeLen; ++l) L += c12 >= fend[l] ? 1u : 0u;  // fend[l] = first code beyond length l
@@ -1513,11 +1521,13 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     }
     STAMP(0);  // header
 
-    // single-symbol entries, one code-length class at a time; table indices are
-    // the top kDecTabBits bits of the left-aligned 12-bit code space
+    // single-symbol entries, one code-length class at a time.  e runs over the
+    // top kDecTabBits bits of the left-aligned 12-bit code space; the entry is
+    // stored at the bit-reversed index (the reader looks codes up bit-reversed)
     uint32_t* const ptab = tab + (pass << kDecTabBits);
     constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
-    static_assert(kTabShift <= 1, "escape entries cover one bit");
+    static_assert(kTabShift <= 1, "sibling entries cover one bit");
+#define HFZ_TIX(e) (__builtin_bitreverse32(e) >> (32 - (kTableFree ? 1 : kDecTabBits)))
     if (kTableFree) {
 #pragma unroll
       for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = __builtin_amdgcn_readfirstlane(fcode[l + 1]);
@@ -1527,6 +1537,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
       uint8_t* const list = (uint8_t*)(tab + 16);
       for (uint32_t i = lane; i < nsym; i += 64) list[i] = syms[i];
     } else if (kF == 1 || p_err == HFZ_OK) {
+      // with sibling entries in the table, a lone symbol sits in bytes 2 and 3
+      constexpr uint32_t kDup = kTabShift ? 0x0101u : 0x0001u;
 #pragma unroll
       for (uint32_t L = 0; L <= kDecTabBits; ++L) {
         if (cnt[L] == 0) continue;
@@ -1534,7 +1546,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #pragma unroll 4
         for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
           const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
-          ptab[e] = L | (8u << 8) | ((uint32_t)syms[j] << 16);
+          ptab[HFZ_TIX(e)] = L | (8u << 8) | (((uint32_t)syms[j] * kDup) << 16);
           l1tab[e] = (uint8_t)L;
         }
       }
@@ -1542,8 +1554,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         const uint32_t lo = fcode[kMaxCodeLen] >> 1;
         for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
           const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
-          ptab[e] = kDecEsc | (uint32_t)kMaxCodeLen | (8u << 8) | ((uint32_t)syms[j] << 16) |
-                    ((uint32_t)syms[j + 1] << 24);
+          ptab[HFZ_TIX(e)] = (uint32_t)kMaxCodeLen | (8u << 8) | ((uint32_t)syms[j] << 16) |
+                             ((uint32_t)syms[j + 1] << 24);
           l1tab[e] = (uint8_t)kMaxCodeLen;
         }
       }
@@ -1558,10 +1570,13 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         const uint32_t L1 = l1tab[e];
         const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
         const uint32_t L2 = l1tab[rem];
-        if (L1 + L2 <= kDecTabBits)
-          ptab[e] = (L1 + L2) | (16u << 8) | (ptab[e] & 0xff0000) | ((ptab[rem] & 0xff0000) << 8);
+        if (L1 + L2 <= kDecTabBits) {
+          uint32_t* const pe = ptab + HFZ_TIX(e);
+          *pe = (L1 + L2) | (16u << 8) | (*pe & 0xff0000) | ((ptab[HFZ_TIX(rem)] & 0xff0000) << 8);
+        }
       }
     }
+#undef HFZ_TIX
     HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
     STAMP(1);  // table
   }
@@ -1570,7 +1585,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     if (k == 0 && status && present) status[f] = err;
     return;
   }
-  const uint32_t* const mytab = tab + (half << kDecTabBits);
+  const uint8_t* const tabb = (const uint8_t*)(tab + (half << kDecTabBits));
+  constexpr uint32_t kTabMask = kTableFree ? 0 : ((1u << kDecTabBits) - 1) << 2;
 
   // Input side: offsets are relative to cbase, a 64-byte aligned address 256
   // bytes below the frame, so that the block arithmetic below (up to three
@@ -1593,7 +1609,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
   const uint32_t out_hi = out_lo + s.size;
 
-  uint32_t* const irow = iring + lane;      // dword d of this lane's input ring: irow[64 * d]
+  uint32_t* const irow = iring + lane;      // row r of this lane's input ring: irow[64 * r]
   uint32_t* const orow32 = obuf_all + lane;  // dword d of its output ring: orow32[64 * d]
 
   // loads block `blk` (offset from cbase) of this lane's stream into registers
@@ -1607,15 +1623,16 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         pre[q_] = *(const uint4*)(cbase + (blk) + 16 * q_);       \
     }                                                             \
   } while (0)
-  // writes the registers into the ring slot of block `blk`
+  // writes the registers, every dword bit-reversed, into the ring rows of block
+  // `blk`: dword j of the block goes to row (blk & 64 ? 0 : 16) + 15 - j
 #define HFZ_STAGE_BLOCK(blk)                                      \
   do {                                                            \
-    uint32_t* d_ = irow + 64 * (((blk) & kDecInBlk) >> 2);        \
+    uint32_t* d_ = irow + 64 * (((blk) & kDecInBlk) ? 0 : 16);    \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {            \
-      d_[64 * (4 * q_)] = pre[q_].x;                              \
-      d_[64 * (4 * q_ + 1)] = pre[q_].y;                          \
-      d_[64 * (4 * q_ + 2)] = pre[q_].z;                          \
-      d_[64 * (4 * q_ + 3)] = pre[q_].w;                          \
+      d_[64 * (15 - 4 * q_)] = __builtin_bitreverse32(pre[q_].x); \
+      d_[64 * (14 - 4 * q_)] = __builtin_bitreverse32(pre[q_].y); \
+      d_[64 * (13 - 4 * q_)] = __builtin_bitreverse32(pre[q_].z); \
+      d_[64 * (12 - 4 * q_)] = __builtin_bitreverse32(pre[q_].w); \
     }                                                             \
   } while (0)
 
@@ -1629,31 +1646,44 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
   STAMP(2);  // priming
 
-  // bit reader (CodeReader, codec/huffman.cpp:502-586): the window is the 8
-  // bytes at ip, of which `used` (< 8 between windows) bits are consumed;
-  // bitbuf = window << used.  `below` holds the 8 bytes under the window, read
-  // from the ring a whole window (four lookups) before they are needed, so the
-  // refill is two shifts and an OR and no LDS read sits on the lookup chain:
-  // after consuming c more bits, the next window is
-  // (bitbuf << c) | (below >> (64 - used - c)).
-  uint32_t ip = g_end - 8;
-  uint32_t used = 0;
-  uint64_t bitbuf = 0, below = 0;
-#define HFZ_READ8(dst, pos)                                                  \
+  // Bit reader (CodeReader, codec/huffman.cpp:502-586).  wlo and whi are the
+  // (reversed) dwords under the bit position, wlo the one being consumed; wnx
+  // is the dword below them, read from the ring a pair of lookups before it is
+  // needed, so no ring read sits on the lookup chain.  sacc = (bits of wlo
+  // consumed) - 2, kept in 0..31 between pairs: the 64-bit shift of whi:wlo by
+  // sacc puts the next code at bits 2.., i.e. times four, which is the byte
+  // offset of its table entry.  Within a pair sacc has whole entries added to
+  // it: the shifts look at its low six bits only, and bit 5 after the pair
+  // says that wlo is used up (a pair consumes at most 24 bits).
+  // ra = 256 * (ring row of wnx), running on without wrapping; ra_low the same
+  // for the lowest staged dword, so ra_low - ra = 256 * (staged dwords below
+  // wnx); ra_area for the dword holding the first byte of the stream area.
+  const uint32_t d_last = (g_end - 1) >> 2;  // dword holding the stream's last byte
+  uint32_t ra = (31u - (d_last - 1)) << 8;
+  uint32_t ra_low = (31u - (low_blk >> 2)) << 8;
+  const uint32_t ra_area = (31u - (area_off >> 2)) << 8;
+  const uint8_t* const icol = (const uint8_t*)irow;
+  constexpr uint32_t kInRowMask = (kDecInDw - 1) << 8;
+  // start one dword up: the bytes of d_last above the stream end and the whole
+  // dword above it count as consumed, and the first refill moves down
+  uint32_t wlo = *(const uint32_t*)(icol + ((ra - 512) & kInRowMask));
+  uint32_t whi = *(const uint32_t*)(icol + ((ra - 256) & kInRowMask));
+  uint32_t wnx = *(const uint32_t*)(icol + (ra & kInRowMask));
+  uint32_t sacc = 32 + 8 * (3 - ((g_end - 1) & 3)) - 2;
+  // after a pair: wlo used up -> whi:wlo <- wnx:whi, and the next wnx is read
+#define HFZ_REFILL()                                                         \
   do {                                                                       \
-    const uint32_t p_ = (pos);                                               \
-    const uint32_t i0_ = (p_ >> 2) & (kDecInDw - 1);                         \
-    const uint32_t d0_ = irow[64 * i0_];                                     \
-    const uint32_t d1_ = irow[64 * ((i0_ + 1) & (kDecInDw - 1))];            \
-    const uint32_t d2_ = irow[64 * ((i0_ + 2) & (kDecInDw - 1))];            \
-    const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1_, d0_, p_ & 3);       \
-    const uint32_t hi_ = __builtin_amdgcn_alignbyte(d2_, d1_, p_ & 3);       \
-    dst = ((uint64_t)hi_ << 32) | lo_;                                       \
+    const uint32_t z_ = sacc & 32;                                           \
+    wlo = z_ ? whi : wlo;                                                    \
+    whi = z_ ? wnx : whi;                                                    \
+    ra = (z_ << 3) + ra; /* v_lshl_add_u32 */                                \
+    sacc &= 31;                                                              \
+    wnx = *(const uint32_t*)(icol + (ra & kInRowMask));                      \
   } while (0)
-  HFZ_READ8(bitbuf, ip);
-  HFZ_READ8(below, ip - 8);
+  HFZ_REFILL();
+
   // output: decoded bytes collect in obuf (sh = 8 * their number, < 32 between
-  // lookup pairs); wp is the output offset of the dword being filled.  That
+  // pairs); wp is the output offset of the dword being filled.  That
   // dword is written to the ring after every pair and simply rewritten until it
   // is complete.  nfb = next 32-byte block to leave the ring.  A full block is
   // read into sb[] at the end of the round that completed it and stored to
@@ -1667,7 +1697,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   constexpr uint32_t kOutRowMask = (kDecOutDw - 1) << 8;
   uint32_t wa = ((wp >> 2) & (kDecOutDw - 1)) << 8;
   uint32_t nfb = out_lo & ~(kDecBlk - 1);
-  uint32_t left = s.size;  // symbols still to produce
+  int32_t left = (int32_t)s.size;  // symbols still to produce; a round may overshoot below zero
   bool stream_bad = false;
   uint32_t sb[8];   // the block at sb_at; with kPair64 the even block of a pair
   uint32_t sb_at = 0;
@@ -1676,45 +1706,39 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   uint32_t sc_at = 0;
   bool sc_full = false;
 
-  // `used` may be anything below 64 here; with used == 0 the OR would bring in
-  // all of `below`, which only happens when nothing was consumed since the last
-  // refill: callers that can get there use the guarded form.
-#define HFZ_REFILL()                                                         \
+  // the entry for the code at the bottom of window t_ (bits 2..)
+#define HFZ_ENTRY(t_)                                                                           \
+  (kTableFree ? table_free_entry(__builtin_bitreverse32((t_) >> 2) >> 20, fend, tab)            \
+              : *(const uint32_t*)(tabb + ((t_) & kTabMask)))
+  // its symbols, w_ = 8 * their number (in bits 0..4; v_bfe_u32 looks no further).
+  // 11-bit table: offset 24 instead of 16 iff the entry counts one symbol (bit 3
+  // of w_) and the 12th bit of the code (bit 13 of t_) is set.
+#define HFZ_SYMS(e_, t_, w_)                                                                    \
+  ((!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen)                                         \
+       ? __builtin_amdgcn_ubfe((e_), ((((t_) >> 10) & (w_)) | 16), (w_))                        \
+       : (e_) >> 16)
+  // two lookups, their symbols appended to obuf, the finished dword written out,
+  // the bit reader moved on
+#define HFZ_PAIR()                                                           \
   do {                                                                       \
-    used &= 63; /* whole entries were added; fewer than 64 bits were consumed */ \
-    bitbuf |= below >> ((64 - used) & 63);                                   \
-    ip -= used >> 3;                                                         \
-    used &= 7;                                                               \
-    HFZ_READ8(below, ip - 8);                                                \
-  } while (0)
-#define HFZ_LOOKUP()                                                         \
-  do {                                                                       \
-    const uint32_t e_ = kTableFree ? table_free_entry(bitbuf, fend, tab)     \
-                                   : mytab[(uint32_t)(bitbuf >> (64 - (kTableFree ? 1 : kDecTabBits)))]; \
-    if (!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen) {                \
-      /* offset 24 iff escape (bit 7 of e_) and the 12th bit (bit 52) is set; \
-         v_bfe_u32 looks at bits 0..4 of offset and width, and of those      \
-         e_ >> 4 can only have bit 3 set (consumed < 16, 8 * count is 8 or   \
-         16) and e_ >> 8 is 8 * count.  sh collects e_ >> 8 whole: its bits  \
-         0..5 are right, which is all the shift and HFZ_DRAIN look at */     \
-      const uint32_t w_ = e_ >> 8;                                           \
-      const uint32_t off_ = (((uint32_t)(bitbuf >> 32) >> 17) & (e_ >> 4)) | 16; \
-      obuf |= (uint64_t)__builtin_amdgcn_ubfe(e_, off_, w_) << (sh & 63);    \
-      sh += w_;                                                              \
-    } else {                                                                 \
-      obuf |= (uint64_t)(e_ >> 16) << sh;                                    \
-      sh += (e_ >> 8) & 0xff;                                                \
-    }                                                                        \
-    bitbuf <<= (e_ & 63);                                                    \
-    used += e_; /* bits 0..5 of the sum are the bits consumed: HFZ_REFILL */ \
-  } while (0)
-#define HFZ_DRAIN()                                                          \
-  do {                                                                       \
+    const uint64_t win_ = ((uint64_t)whi << 32) | wlo;                       \
+    const uint32_t t1_ = (uint32_t)(win_ >> (sacc & 63));                    \
+    const uint32_t e1_ = HFZ_ENTRY(t1_);                                     \
+    sacc += e1_;                                                             \
+    const uint32_t t2_ = (uint32_t)(win_ >> (sacc & 63));                    \
+    const uint32_t e2_ = HFZ_ENTRY(t2_);                                     \
+    sacc += e2_;                                                             \
+    const uint32_t w1_ = e1_ >> 8, w2_ = e2_ >> 8;                           \
+    const uint32_t y1_ = HFZ_SYMS(e1_, t1_, w1_);                            \
+    const uint32_t y2_ = HFZ_SYMS(e2_, t2_, w2_);                            \
+    obuf |= (uint64_t)(y1_ | (y2_ << (w1_ & 31))) << sh;                     \
+    sh += w1_ + w2_;                                                         \
     *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;                \
     const uint32_t f_ = sh & 32;                                             \
     obuf >>= f_;                                                             \
     wa += f_ << 3;                                                           \
     sh &= 31;                                                                \
+    HFZ_REFILL();                                                            \
   } while (0)
   // moves the ring block holding output offsets [nfb, nfb+32) into sb[]
 #define HFZ_TAKE_BLOCK()                                                     \
@@ -1751,69 +1775,46 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     }                                                                        \
   } while (0)
 
-  // A round moves ip down by at most 24 bytes and its last refill reads the 8
-  // bytes below that: a lane can run a round when [ip-32, ip) is staged.
-  constexpr uint32_t kReach = 32;
-  bool can = false;
-  while (__any(left > 0)) {
-    if (left > 0 && ip - kReach < low_blk) {  // out of staged input: next block
-      low_blk -= kDecInBlk;
-      HFZ_STAGE_BLOCK(low_blk);
-      HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
+  // A round moves the reader down by at most kDecRoundDw dwords and its last
+  // refill reads the dword below: a lane can run a round when that many dwords
+  // below wnx are staged.
+  constexpr int32_t kReach = (int32_t)(kDecRoundDw << 8);
+  for (;;) {
+    if (!__any(left > 0)) break;
+    if (left > 0 && (int32_t)(ra_low - ra) < kReach) {  // out of staged input: next block
+      // A reader that still owes symbols is above the stream area, so it only
+      // asks for a block when fewer than kDecRoundDw dwords between the lowest
+      // staged one and the area are left; anything else is a corrupt stream.
+      if ((int32_t)(ra_low - ra_area) >= kReach) {
+        stream_bad = true;
+        left = 0;
+      } else {
+        low_blk -= kDecInBlk;
+        ra_low += (kDecInBlk / 4) << 8;
+        HFZ_STAGE_BLOCK(low_blk);
+        HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
+      }
     }
-    can = left > 0;
     STAMP(3);  // staging
-    while (__any(can)) {
-      const bool ran = can;
+    for (;;) {
+      const bool can = left > 0 && (int32_t)(ra_low - ra) >= kReach;
+      if (!__any(can)) break;
+      bool full = false;  // this round completed the block at nfb
       if (can) {
-        if (left >= 2 * kDecRound) {
-          // fast round: every lookup may emit two symbols without bounds checks
-          const uint32_t wa_b = wa, sh_b = sh;
+        const uint32_t wa_b = wa, sh_b = sh;
 #pragma unroll
-          for (uint32_t j = 0; j < kDecRound / 4; ++j) {
-            HFZ_LOOKUP();
-            HFZ_LOOKUP();
-            HFZ_DRAIN();
-            HFZ_LOOKUP();
-            HFZ_LOOKUP();
-            HFZ_DRAIN();
-            HFZ_REFILL();
-          }
-          const uint32_t adv = wa - wa_b;  // 256 per dword = 64 per byte
-          left -= ((adv >> 3) + sh - sh_b) >> 3;
-          wp += adv >> 6;
-        } else {
-          // last symbols of the slice; the final one may be the first half of
-          // a two-symbol entry (Decode1, codec/huffman.cpp:875-878)
-          const uint32_t wa_b = wa;
-          for (uint32_t j = 0; j < kDecRound && left > 0; ++j) {
-            uint32_t e = kTableFree ? table_free_entry(bitbuf, fend, tab)
-                                    : mytab[(uint32_t)(bitbuf >> (64 - (kTableFree ? 1 : kDecTabBits)))];
-            if (!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen && (e & kDecEsc)) e = resolve_escape(e, bitbuf);
-            uint32_t ns = (e >> 11) & 3;
-            uint32_t pair = e >> 16;
-            if (ns > left) {
-              ns = 1;
-              pair &= 0xff;
-            }
-            obuf |= (uint64_t)pair << sh;
-            sh += 8 * ns;
-            left -= ns;
-            bitbuf <<= (e & 63);
-            used += e & 63;
-            HFZ_DRAIN();
-            if ((j & 3) == 3) HFZ_REFILL();
-          }
-          if (used >= 8) HFZ_REFILL();
-          wp += (wa - wa_b) >> 6;
-        }
+        for (uint32_t j = 0; j < kDecRound / 2; ++j) HFZ_PAIR();
+        const uint32_t adv = wa - wa_b;  // 256 per dword = 64 per byte
+        left -= (int32_t)(((adv >> 3) + sh - sh_b) >> 3);
+        wp += adv >> 6;
+        full = wp >= nfb + kDecBlk;
         // last round's block goes to memory, the one this round filled is read
         if (kStore == 2) {
           // handled after the round, by all lanes (below)
         } else if (!kPair64) {
           if (sb_full) HFZ_STORE_BLOCK();
-          sb_full = wp >= nfb + kDecBlk;
-          if (sb_full) HFZ_TAKE_BLOCK();
+          sb_full = full;
+          if (full) HFZ_TAKE_BLOCK();
         } else {
           // an even block waits for the odd one above it; blocks are taken in
           // address order, so when both are held they are neighbours
@@ -1829,7 +1830,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
             }
             sb_full = sc_full = false;
           }
-          if (wp >= nfb + kDecBlk) {
+          if (full) {
             if (nfb & kDecBlk) {
               HFZ_TAKE_ODD_BLOCK();
               sc_full = true;
@@ -1839,11 +1840,6 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
             }
           }
         }
-        if (ip < area_off) {  // ran below the stream area: corrupt stream
-          stream_bad = true;
-          left = 0;
-        }
-        can = left > 0 && ip - kReach >= low_blk;
       }
       if (kStore == 2) {
         // A round adds at most 32 bytes, so at most one more block is complete.
@@ -1851,7 +1847,6 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         // lanes fetch one 16-byte half each from the owner's ring rows and store
         // them side by side.  First and last block of a slice (they may hold a
         // neighbour's bytes) are stored by their owner alone, byte-clipped.
-        const bool full = ran && wp >= nfb + kDecBlk;
         if (__ballot(full)) {
           wave_sync();  // ring rows written in the round are read by the neighbour lane
           const bool whole = nfb >= out_lo && nfb + kDecBlk <= out_hi;
@@ -1894,11 +1889,11 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
       HFZ_STORE_BLOCK();
     }
   }
-#undef HFZ_READ8
 #undef HFZ_REFILL
+#undef HFZ_ENTRY
+#undef HFZ_SYMS
+#undef HFZ_PAIR
 #undef HFZ_TAKE_BLOCK
-#undef HFZ_LOOKUP
-#undef HFZ_DRAIN
 #undef HFZ_STORE_BLOCK
 #undef HFZ_TAKE_ODD_BLOCK
 #undef HFZ_STORE_ODD_BLOCK

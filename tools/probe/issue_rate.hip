@@ -70,6 +70,18 @@ KERNEL(k_lds_rd64_rand, "ds_read_b64 %4, %6\n", "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_mix_rd_wr, "ds_read_b32 %1, %6\n ds_write_b16 %6, %2\n", "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_saveexec, "v_cmp_gt_i32 vcc, 0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n", "")
 
+KERNEL(k_cnd_cmp, "v_cmp_gt_i32 vcc, 0, %2\n v_cndmask_b32 %1, %1, %0, vcc\n", "")
+KERNEL(k_cnd_e64, "v_cndmask_b32_e64 %1, %1, %0, s[20:21]\n", "")
+KERNEL(k_cnd_ind, "v_cndmask_b32 %1, %2, %0, vcc\n v_cndmask_b32 %3, %2, %0, vcc\n", "")
+KERNEL(k_bfi, "v_bfi_b32 %1, %0, %1, %2\n", "")
+KERNEL(k_bfe_i, "v_bfe_i32 %1, %1, 5, 1\n", "")
+KERNEL(k_bfrev, "v_bfrev_b32 %1, %1\n", "")
+KERNEL(k_mix10_rd, "ds_read_b32 %3, %6\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_mix10_wr, "ds_write_b32 %6, %2\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n", "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_mix10_vop3, "v_or3_b32 %3, %3, %0, %2\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n", "")
+KERNEL(k_mix_vop3_2, "v_or3_b32 %3, %3, %0, %2\n v_add_u32 %1, %1, %0\n", "")
+KERNEL(k_add10, "v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n v_add_u32 %1, %1, %0\n", "")
+
 typedef void (*kern_t)(uint32_t*, int);
 struct Item { const char* name; kern_t k; int per_rep; };
 
@@ -98,7 +110,11 @@ int main(int argc, char** argv) {
       {"ds_write_b16 random", k_lds_wr16_rand, 1}, {"ds_write_b16_d16_hi random", k_lds_wr16hi_rand, 1},
       {"ds_write_b8 random", k_lds_wr8_rand, 1}, {"ds_write_b64 linear", k_lds_wr64_lin, 1},
       {"ds_read_u16 random", k_lds_rd_u16_rand, 1}, {"ds_read_b64 random", k_lds_rd64_rand, 1},
-      {"mix: ds_read_b32 + ds_write_b16 random", k_mix_rd_wr, 1}};
+      {"mix: ds_read_b32 + ds_write_b16 random", k_mix_rd_wr, 1},
+      {"v_cmp + v_cndmask (vcc)", k_cnd_cmp, 1}, {"v_cndmask_b32_e64 sgpr mask", k_cnd_e64, 1},
+      {"v_cndmask indep x2", k_cnd_ind, 2}, {"v_bfi_b32", k_bfi, 1}, {"v_bfe_i32", k_bfe_i, 1}, {"v_bfrev_b32", k_bfrev, 1},
+      {"10 v_add", k_add10, 1}, {"mix: ds_read + 10 v_add", k_mix10_rd, 1}, {"mix: ds_write + 10 v_add", k_mix10_wr, 1},
+      {"mix: v_or3 + 4 v_add", k_mix10_vop3, 1}, {"mix: v_or3 + v_add", k_mix_vop3_2, 1}};
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
