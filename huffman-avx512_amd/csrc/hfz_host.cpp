@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -506,6 +507,12 @@ int hfz_set_encoder_block(int bytes) {
   return HFZ_OK;
 }
 
+int hfz_set_encoder_parts(int n) {
+  if (n < 0 || n > 64) return HFZ_E_ARG;
+  g_encoder_parts = n;
+  return HFZ_OK;
+}
+
 int hfz_set_decoder_store(int mode) {
   if (mode < 0 || mode > 2) return HFZ_E_ARG;
   g_decoder_store = mode;
@@ -576,6 +583,92 @@ struct DevBuf {
   }
   hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
+
+// Buffers of the host-buffer entry points (hfz_compress / hfz_decompress): one
+// device allocation, one pinned host allocation and one stream, kept between
+// calls so that a call costs two copies, the kernels and ONE synchronisation
+// instead of four allocations and three blocking copies.  A call takes an
+// arena of the current device from a pool (or makes one) and puts it back, so
+// concurrent callers never share one; an arena that grew beyond kArenaKeep is
+// freed instead of pooled.  Pooled arenas live until the process ends.
+constexpr size_t kArenaKeep = size_t(256) << 20;
+struct Arena {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  uint8_t* dev = nullptr;
+  size_t dev_bytes = 0;
+  uint8_t* pin = nullptr;
+  size_t pin_bytes = 0;
+  hipError_t reserve(size_t dev_need, size_t pin_need) {
+    if (!stream) {
+      hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
+    if (dev_need > dev_bytes) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr;
+      dev_bytes = 0;
+      const size_t want = dev_need + dev_need / 4;
+      hipError_t e = hipMalloc((void**)&dev, want);
+      if (e != hipSuccess) return e;
+      dev_bytes = want;
+    }
+    if (pin_need > pin_bytes) {
+      if (pin) (void)hipHostFree(pin);
+      pin = nullptr;
+      pin_bytes = 0;
+      const size_t want = pin_need + pin_need / 4;
+      hipError_t e = hipHostMalloc((void**)&pin, want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      pin_bytes = want;
+    }
+    return hipSuccess;
+  }
+  void release() {
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    if (stream) (void)hipStreamDestroy(stream);
+    dev = pin = nullptr;
+    stream = nullptr;
+    dev_bytes = pin_bytes = 0;
+  }
+};
+std::mutex g_arena_mutex;
+std::vector<Arena>* arena_pool() {
+  static std::vector<Arena>* pool = new std::vector<Arena>();  // never destroyed: HIP may be gone at exit
+  return pool;
+}
+// RAII handle: takes an arena of the current device, returns it on scope exit
+struct ArenaLease {
+  Arena a;
+  bool ok = false;
+  ArenaLease() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    ok = true;
+    std::lock_guard<std::mutex> g(g_arena_mutex);
+    auto& pool = *arena_pool();
+    for (size_t i = 0; i < pool.size(); ++i) {
+      if (pool[i].device == dev) {
+        a = pool[i];
+        pool[i] = pool.back();
+        pool.pop_back();
+        return;
+      }
+    }
+    a.device = dev;
+  }
+  ~ArenaLease() {
+    if (!ok) return;
+    if (a.dev_bytes + a.pin_bytes > kArenaKeep) {
+      a.release();
+      return;
+    }
+    std::lock_guard<std::mutex> g(g_arena_mutex);
+    arena_pool()->push_back(a);
+  }
+};
+size_t up256(size_t n) { return (n + 255) & ~size_t(255); }
 }  // namespace
 
 int hfz_histogram(const void* src, size_t n, uint32_t hist[256]) {
@@ -597,28 +690,50 @@ int hfz_compress(int K, const void* src, size_t n, void* dst, size_t cap, size_t
   if (!have_device()) return HFZ_E_NO_DEVICE;
   const size_t bound = hfz_compress_bound(n, K);
   const size_t ws_bytes = hfz_workspace_bytes(K, 1);
-  DevBuf d_raw, d_comp, d_ws, d_meta;
-  HFZ_HIP(d_raw.alloc(n));
-  HFZ_HIP(d_comp.alloc(bound));
-  HFZ_HIP(d_ws.alloc(ws_bytes));
-  HFZ_HIP(d_meta.alloc(32));
-  if (n) HFZ_HIP(hipMemcpy(d_raw.p, src, n, hipMemcpyHostToDevice));
-  uint64_t* d_off = (uint64_t*)d_meta.p;
-  uint32_t* d_size = (uint32_t*)((uint8_t*)d_meta.p + 8);
-  int32_t* d_status = (int32_t*)((uint8_t*)d_meta.p + 16);
-  int rc = hfz_compress_batch_dev(K, d_raw.p, n, n ? n : 1, d_comp.p, bound, 0, d_off, d_size,
-                                  d_status, d_ws.p, ws_bytes, nullptr);
-  if (rc != HFZ_OK) return rc;
-  uint8_t meta[32];
-  HFZ_HIP(hipMemcpy(meta, d_meta.p, 32, hipMemcpyDeviceToHost));
+  // device: raw | meta (32 bytes) + frame, contiguous so that one copy brings both back | workspace
+  const size_t o_meta = up256(n), o_comp = o_meta + 32, o_ws = up256(o_comp + bound);
+  // Frames of up to kOneCopy bytes come back in a single copy of meta + bound
+  // (the size is not known before the kernels have run); larger ones fetch the
+  // 32 bytes first and then exactly the frame.
+  constexpr size_t kOneCopy = size_t(1) << 20;
+  const bool one_copy = bound <= kOneCopy;
+  constexpr size_t kStaged = size_t(4) << 20;  // larger inputs are copied from the caller's memory directly
+  const bool staged = n <= kStaged;
+  ArenaLease lease;
+  if (!lease.ok) return HFZ_E_HIP;
+  Arena& ar = lease.a;
+  HFZ_HIP(ar.reserve(o_ws + ws_bytes, std::max(staged ? n : size_t(0), 32 + (one_copy ? bound : size_t(0)))));
+  hipStream_t st = ar.stream;
+  if (n) {
+    if (staged) std::memcpy(ar.pin, src, n);
+    HFZ_HIP(hipMemcpyAsync(ar.dev, staged ? (const void*)ar.pin : src, n, hipMemcpyHostToDevice, st));
+  }
+  uint64_t* d_off = (uint64_t*)(ar.dev + o_meta);
+  uint32_t* d_size = (uint32_t*)(ar.dev + o_meta + 8);
+  int32_t* d_status = (int32_t*)(ar.dev + o_meta + 16);
+  int rc = hfz_compress_batch_dev(K, ar.dev, n, n ? n : 1, ar.dev + o_comp, bound, 0, d_off, d_size,
+                                  d_status, ar.dev + o_ws, ws_bytes, st);
+  if (rc != HFZ_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  // the input has been consumed by the time the results are copied (same stream), so the
+  // pinned buffer is reused for them
+  HFZ_HIP(hipMemcpyAsync(ar.pin, ar.dev + o_meta, 32 + (one_copy ? bound : 0), hipMemcpyDeviceToHost, st));
+  HFZ_HIP(hipStreamSynchronize(st));
   uint32_t size;
   int32_t status;
-  std::memcpy(&size, meta + 8, 4);
-  std::memcpy(&status, meta + 16, 4);
+  std::memcpy(&size, ar.pin + 8, 4);
+  std::memcpy(&status, ar.pin + 16, 4);
   if (status != HFZ_OK) return status;
   *out_n = size;
   if (size > cap) return HFZ_E_CAPACITY;
-  HFZ_HIP(hipMemcpy(dst, d_comp.p, size, hipMemcpyDeviceToHost));
+  if (one_copy) {
+    std::memcpy(dst, ar.pin + 32, size);
+  } else {
+    HFZ_HIP(hipMemcpyAsync(dst, ar.dev + o_comp, size, hipMemcpyDeviceToHost, st));
+    HFZ_HIP(hipStreamSynchronize(st));
+  }
   return HFZ_OK;
 }
 
@@ -639,27 +754,49 @@ int hfz_decompress(int K, const void* src, size_t n, void* dst, size_t cap, size
   *out_n = raw_size;
   if (raw_size > cap) return HFZ_E_CAPACITY;
   if (raw_size > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
-  if (!have_device()) return HFZ_E_NO_DEVICE;
-  DevBuf d_comp, d_raw, d_meta;
-  HFZ_HIP(d_comp.alloc(n));
-  HFZ_HIP(d_raw.alloc(raw_size));
-  HFZ_HIP(d_meta.alloc(32));
-  HFZ_HIP(hipMemcpy(d_comp.p, src, n, hipMemcpyHostToDevice));
-  uint8_t meta[32] = {};
-  const uint32_t size32 = (uint32_t)n;
   if (n > 0xffffffffull) return HFZ_E_TOO_LARGE;
-  std::memcpy(meta + 8, &size32, 4);
-  HFZ_HIP(hipMemcpy(d_meta.p, meta, 32, hipMemcpyHostToDevice));
-  rc = hfz_decompress_batch_dev(K, d_comp.p, n, (const uint64_t*)d_meta.p,
-                                (const uint32_t*)((uint8_t*)d_meta.p + 8), 1, d_raw.p, raw_size,
-                                raw_size ? raw_size : 1, (int32_t*)((uint8_t*)d_meta.p + 16),
-                                nullptr);
-  if (rc != HFZ_OK) return rc;
-  HFZ_HIP(hipMemcpy(meta, d_meta.p, 32, hipMemcpyDeviceToHost));
+  if (!have_device()) return HFZ_E_NO_DEVICE;
+  // device: meta (32 bytes) + frame, sent in one copy | meta back + raw, fetched in one copy
+  const size_t o_comp = 32, o_back = up256(o_comp + n), o_raw = o_back + 32;
+  // large frames go to and from the caller's memory directly, small ones through the pinned buffer
+  constexpr size_t kStaged = size_t(4) << 20;
+  const bool staged = n <= kStaged && raw_size <= kStaged;
+  ArenaLease lease;
+  if (!lease.ok) return HFZ_E_HIP;
+  Arena& ar = lease.a;
+  HFZ_HIP(ar.reserve(o_raw + raw_size, 32 + (staged ? std::max(n, raw_size) : size_t(0))));
+  hipStream_t st = ar.stream;
+  std::memset(ar.pin, 0, 32);
+  const uint32_t size32 = (uint32_t)n;
+  std::memcpy(ar.pin + 8, &size32, 4);
+  if (staged) {
+    std::memcpy(ar.pin + 32, src, n);
+    HFZ_HIP(hipMemcpyAsync(ar.dev, ar.pin, 32 + n, hipMemcpyHostToDevice, st));
+  } else {
+    HFZ_HIP(hipMemcpyAsync(ar.dev, ar.pin, 32, hipMemcpyHostToDevice, st));
+    HFZ_HIP(hipMemcpyAsync(ar.dev + o_comp, src, n, hipMemcpyHostToDevice, st));
+  }
+  int32_t* d_status = (int32_t*)(ar.dev + o_back + 16);
+  rc = hfz_decompress_batch_dev(K, ar.dev + o_comp, n, (const uint64_t*)ar.dev, (const uint32_t*)(ar.dev + 8), 1,
+                                ar.dev + o_raw, raw_size, raw_size ? raw_size : 1, d_status, st);
+  if (rc != HFZ_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
   int32_t status;
-  std::memcpy(&status, meta + 16, 4);
-  if (status != HFZ_OK) return status;
-  if (raw_size) HFZ_HIP(hipMemcpy(dst, d_raw.p, raw_size, hipMemcpyDeviceToHost));
+  if (staged) {
+    HFZ_HIP(hipMemcpyAsync(ar.pin, ar.dev + o_back, 32 + raw_size, hipMemcpyDeviceToHost, st));
+    HFZ_HIP(hipStreamSynchronize(st));
+    std::memcpy(&status, ar.pin + 16, 4);
+    if (status != HFZ_OK) return status;
+    if (raw_size) std::memcpy(dst, ar.pin + 32, raw_size);
+  } else {
+    HFZ_HIP(hipMemcpyAsync(ar.pin, ar.dev + o_back, 32, hipMemcpyDeviceToHost, st));
+    if (raw_size) HFZ_HIP(hipMemcpyAsync(dst, ar.dev + o_raw, raw_size, hipMemcpyDeviceToHost, st));
+    HFZ_HIP(hipStreamSynchronize(st));
+    std::memcpy(&status, ar.pin + 16, 4);
+    if (status != HFZ_OK) return status;
+  }
   return HFZ_OK;
 }
 

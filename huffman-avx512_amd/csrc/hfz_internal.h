@@ -62,6 +62,8 @@ extern std::atomic<int> g_decoder_table_bits;
 extern std::atomic<int> g_frames_per_wave;
 // 0 = choose by frame count, 32 / 64 = forced (hfz_set_encoder_block).
 extern std::atomic<int> g_encoder_block;
+// 0 = choose by batch size, n = up to n threads per stream (hfz_set_encoder_parts).
+extern std::atomic<int> g_encoder_parts;
 // 0 = choose by batch size, 1 / 2 = forced (hfz_set_decoder_store).
 extern std::atomic<int> g_decoder_store;
 

@@ -1038,28 +1038,55 @@ constexpr uint32_t kEncGroup = 4;    // input blocks loaded at once per lane
 // larger pieces of a line reach memory (18 % faster at 1 GiB and beyond), 32
 // when every SIMD has a single wave and the shorter wait for the ring reads
 // matters more (9 % faster at 1024 frames).
-template <uint32_t kF, uint32_t kEncOutBlk>
-__global__ __launch_bounds__(64) void encode_kernel(
+//
+// kParts: several threads per stream, for batches with too few frames to fill
+// the chip one wave per frame (and for single frames).  A workgroup of up to
+// 512 threads takes one frame; thread t encodes part t % P of stream t / P
+// (P = 2^log2_parts parts per stream, cut like SliceSizes cuts the frame).  A
+// part's codes have to start at the bit where the previous part's end: every
+// thread first adds up the code lengths of its part, a prefix sum over the P
+// threads of a stream (neighbouring lanes of one wave) gives each part its
+// first bit B, and then the part is written like a stream of its own whose
+// bytes run from end - (B >> 3) down to end - (B' >> 3), B' being the first
+// bit of the next part.  A byte in which two parts meet belongs to the later
+// one, which fetches the bits above its own from the symbols before its part
+// (at most seven codes); the earlier part's bits of that byte, like the
+// padding and the slop that every writer appends, fall outside its byte range
+// and are clipped by the block stores.  The result is the same bytes as one
+// lane per stream (codec/huffman.cpp:825-843).
+template <uint32_t kF, uint32_t kEncOutBlk, bool kParts>
+__global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     uint64_t n_frames, const FrameCode* __restrict__ code, uint32_t code_step,
     const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
-    uint8_t* __restrict__ comp, uint64_t cap) {
+    uint8_t* __restrict__ comp, uint64_t cap, uint32_t log2_parts) {
   static_assert(kF == 1 || kF == 2, "one or two frames per wave");
+  static_assert(!kParts || kF == 1, "parts: one frame per workgroup");
   static_assert(kEncOutBlk == 32 || kEncOutBlk == 64, "the ring holds four or two blocks");
   __shared__ uint32_t enc_all[kF * 256];
-  __shared__ uint32_t oring[64 * kEncRingDw];
-  const uint32_t lane = threadIdx.x;
+  // one output ring per wave: with parts the launch sizes it (dynamic LDS), so
+  // that small workgroups do not hold the LDS of the largest
+  __shared__ uint32_t oring_one[kParts ? 1 : 64 * kEncRingDw];
+  extern __shared__ uint32_t oring_dyn[];
+  uint32_t* const oring = kParts ? oring_dyn : oring_one;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
   const uint32_t half = kF == 1 ? 0 : lane >> 5;
-  const uint32_t k = kF == 1 ? lane : lane & 31;  // stream index within the frame
-  constexpr uint32_t kSub = 64 / kF;              // lanes per frame
+  // stream index within the frame, part index within the stream
+  const uint32_t k = kParts ? tid >> log2_parts : (kF == 1 ? lane : lane & 31);
+  const uint32_t n_parts = kParts ? 1u << log2_parts : 1u;
+  const uint32_t part = kParts ? tid & (n_parts - 1) : 0u;
+  // threads that share the frame's table and header work, and this thread's index among them
+  const uint32_t n_sub = kParts ? blockDim.x : 64 / kF;
+  const uint32_t ti = kParts ? tid : k;
   const uint64_t f_real = (uint64_t)blockIdx.x * kF + half;
   const bool present = f_real < n_frames;
   const uint64_t f = present ? f_real : 0;
   uint32_t* const enc = enc_all + 256 * half;
   STAMP_DECL();
   const FrameCode& fc = code[f * code_step];
-  for (uint32_t i = k; i < 256; i += kSub) {
+  for (uint32_t i = ti; i < 256; i += n_sub) {
     const uint32_t e = fc.enc[i];
     enc[i] = ((e >> 4) << 20) | (e & 15);
   }
@@ -1074,11 +1101,12 @@ __global__ __launch_bounds__(64) void encode_kernel(
 
   // header: raw_size | len_mask | counts | sorted symbols | K-1 end offsets
   if (ok) {
-    if (k < 4) out[k] = (uint8_t)(n >> (8 * k));
-    for (uint32_t i = k; i < hdr_len; i += kSub) out[4 + i] = fc.hdr[i];
-    if (k < K - 1) store_u32u(out + 4 + hdr_len + 4 * k, stream_end[f * 64 + k]);
+    if (ti < 4) out[ti] = (uint8_t)(n >> (8 * ti));
+    for (uint32_t i = ti; i < hdr_len; i += n_sub) out[4 + i] = fc.hdr[i];
+    if (ti < K - 1) store_u32u(out + 4 + hdr_len + 4 * ti, stream_end[f * 64 + ti]);
   }
-  wave_sync();  // enc[] complete
+  if (kParts) __syncthreads();
+  else wave_sync();  // enc[] complete
   STAMP(0);  // table + header
   if (!ok || k >= K) return;
 
@@ -1090,24 +1118,107 @@ __global__ __launch_bounds__(64) void encode_kernel(
   uint8_t* const obase = out - ((uintptr_t)out & (kEncOutBlk - 1));
   const Slice s = slice_of(n, K, k);
   const uint32_t area = (uint32_t)((uintptr_t)out - (uintptr_t)obase) + hdr_total;
-  const uint32_t r_hi = area + stream_end[f * 64 + k];
-  const uint32_t r_lo = area + (k ? stream_end[f * 64 + k - 1] : 0);
-  const uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
-  const uint32_t in_hi = in_lo + s.size;
+  uint32_t r_hi = area + stream_end[f * 64 + k];
+  uint32_t r_lo = area + (k ? stream_end[f * 64 + k - 1] : 0);
+  uint32_t in_lo = (uint32_t)((uintptr_t)frame_in - (uintptr_t)ibase) + s.begin;
+  uint32_t in_hi = in_lo + s.size;
+  uint32_t lead = 0, lead_n = 0;  // parts: the bits above this part's in its first byte
+  if (kParts) {
+    const Slice ps = slice_of(s.size, n_parts, part);
+    const uint32_t slice_lo = in_lo;
+    in_lo += ps.begin;
+    in_hi = in_lo + ps.size;
+    // code bits of the part: whole table entries are added up, sixteen at a
+    // time (bits 4..19 of an entry are zero, so the low bits are the lengths'
+    // sum).  The part is read in groups of four aligned 16-byte blocks with the
+    // next group in flight; addresses past the part are clamped to its last block.
+    uint32_t bits = 0;
+    {
+      const uint32_t first16 = in_lo & ~15u;
+      const uint32_t n16 = ps.size ? ((in_hi + 15) >> 4) - (in_lo >> 4) : 0;
+      const uint32_t last16 = n16 ? first16 + 16 * (n16 - 1) : first16;
+      const uint32_t n_groups = (n16 + 3) / 4;
+      uint4 cur4[4], nxt4[4];
+#define HFZ_LOAD4(dst, g)                                            \
+  do {                                                               \
+    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4; ++q_) {          \
+      uint32_t a_ = first16 + 16 * (4 * (g) + q_);                   \
+      a_ = a_ < last16 ? a_ : last16;                                \
+      dst[q_] = *(const uint4*)(ibase + a_);                         \
+    }                                                                \
+  } while (0)
+      if (n_groups) HFZ_LOAD4(nxt4, 0);
+      for (uint32_t g = 0; g < n_groups; ++g) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) cur4[q] = nxt4[q];
+        if (g + 1 < n_groups) HFZ_LOAD4(nxt4, g + 1);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+          const uint32_t a = first16 + 16 * (4 * g + q);
+          if (a > last16) break;
+          const uint32_t w[4] = {cur4[q].x, cur4[q].y, cur4[q].z, cur4[q].w};
+          uint32_t sum = 0;
+          if (a >= in_lo && a + 16 <= in_hi) {
+#pragma unroll
+            for (uint32_t d = 0; d < 4; ++d)
+              sum += enc[w[d] & 0xff] + enc[(w[d] >> 8) & 0xff] + enc[(w[d] >> 16) & 0xff] + enc[w[d] >> 24];
+          } else {
+#pragma unroll
+            for (uint32_t d = 0; d < 4; ++d) {
+#pragma unroll
+              for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t pos = a + 4 * d + j;
+                if (pos >= in_lo && pos < in_hi) sum += enc[(w[d] >> (8 * j)) & 0xff];
+              }
+            }
+          }
+          bits += sum & 0xfffffu;
+        }
+      }
+#undef HFZ_LOAD4
+    }
+    // first bit of every part: prefix sum over the threads of the stream
+    uint32_t incl = bits;
+    for (uint32_t d = 1; d < n_parts; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, (int)n_parts);
+      if (part >= d) incl += o;
+    }
+    const uint32_t first_bit = incl - bits;
+    const uint32_t stream_hi = r_hi;
+    r_hi = stream_hi - (first_bit >> 3);
+    if (part != n_parts - 1) r_lo = stream_hi - (incl >> 3);
+    lead_n = first_bit & 7;
+    // the lead_n bits before the part: the ends of the codes of the symbols before it
+    uint32_t have = 0;
+    for (uint32_t q = in_lo; have < lead_n && q > slice_lo;) {
+      --q;
+      const uint32_t e = enc[ibase[q]];
+      const uint32_t len = e & 15;
+      if (len) lead |= ((e >> 20) >> (12 - len)) << have;
+      have += len;
+    }
+    lead &= (1u << lead_n) - 1;
+    // a part whose bits all lie in bytes that later parts own has nothing to write
+    if (r_lo >= r_hi) return;
+  }
 
-  uint8_t* const ocol = (uint8_t*)(oring + lane);  // row r of this lane: ocol + 256 * r
+  uint8_t* const ocol = (uint8_t*)(oring + (kParts ? (tid >> 6) * 64 * kEncRingDw : 0u) + lane);  // row r of this lane: ocol + 256 * r
   // bit writer: acc holds nb (< 32 between pairs) pending bits MSB first.  The
   // dword being filled sits at output offset wp - 4; ua is 256 times its ring
   // row, not wrapped (wp = wp0 - (ua - ua0) / 64).  If the stream does not end
   // on a dword boundary the bytes above its end count as already written.
   uint64_t acc = 0;
   uint32_t nb = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
+  if (kParts && lead_n) {
+    acc = ((uint64_t)lead << (64 - lead_n)) >> nb;
+    nb += lead_n;
+  }
   const uint32_t wp0 = (r_hi + 3) & ~3u;
   const uint32_t ua0 = ((~((wp0 - 4) >> 2)) & (kEncRingDw - 1)) << 8;
   uint32_t ua = ua0;
   uint32_t nf = (r_hi - 1) & ~(kEncOutBlk - 1);  // next block to store (descending)
   const uint32_t nf_last = r_lo & ~(kEncOutBlk - 1);
-  bool nf_live = true;
+  bool nf_live = r_lo < r_hi;  // always true for a whole stream (it has its 8 bytes of slop)
   constexpr uint32_t kRowMask = (kEncRingDw - 1) << 8;
 
   // Merges two table entries and appends them.  The current dword is written
@@ -1146,7 +1257,7 @@ __global__ __launch_bounds__(64) void encode_kernel(
     uint32_t sb_[kDw_];                                                       \
     _Pragma("unroll") for (int q_ = 0; q_ < kDw_; ++q_)                       \
       sb_[q_] = *(const uint32_t*)(g_ + 256 * (kDw_ - 1 - q_));               \
-    if ((blk) >= r_lo && (blk) + kEncOutBlk <= r_hi) {                        \
+    if ((blk) >= r_lo && (blk) <= r_hi && r_hi - (blk) >= kEncOutBlk) {       \
       _Pragma("unroll") for (int q_ = 0; q_ < kDw_ / 4; ++q_)                 \
         *(uint4*)(obase + (blk) + 16 * q_) =                                  \
             make_uint4(sb_[4 * q_], sb_[4 * q_ + 1], sb_[4 * q_ + 2], sb_[4 * q_ + 3]); \
@@ -1964,6 +2075,7 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 std::atomic<int> g_decoder_table_bits{0};
 std::atomic<int> g_frames_per_wave{0};
 std::atomic<int> g_encoder_block{0};
+std::atomic<int> g_encoder_parts{0};
 std::atomic<int> g_decoder_store{0};
 
 // ---------------------------------------------------------------------------
@@ -2069,6 +2181,26 @@ int device_cus() {
   return cus;
 }
 
+// Parts per stream (as a power of two) for a batch: none while one wave per
+// frame fills the chip four waves per CU, else as many as it takes to get there,
+// within 512 threads per frame and no less than 512 bytes per part.
+uint32_t encoder_log2_parts(int K, uint64_t n_frames, uint64_t frame_bytes) {
+  const int forced = g_encoder_parts.load(std::memory_order_relaxed);
+  uint32_t max_log2 = 0;
+  while (max_log2 < 6 && ((uint64_t)K << (max_log2 + 1)) <= 512) ++max_log2;
+  if (forced > 0) {
+    uint32_t l = 0;
+    while ((2u << l) <= (uint32_t)forced) ++l;
+    return l < max_log2 ? l : max_log2;
+  }
+  const uint64_t want_threads = 4ull * 64 * (uint64_t)device_cus();
+  uint32_t l = 0;
+  while (l < max_log2 && (n_frames * (uint64_t)K << l) < want_threads &&
+         frame_bytes / ((uint64_t)K << (l + 1)) >= 512)
+    ++l;
+  return l;
+}
+
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
@@ -2079,15 +2211,31 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
   const int enc_blk = g_encoder_block.load(std::memory_order_relaxed);
   const bool wide = enc_blk ? enc_blk == 64
                             : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
+  const uint32_t log2_parts = pair ? 0 : encoder_log2_parts(K, n_frames, frame_bytes);
   const dim3 grid((uint32_t)(pair ? (n_frames + 1) / 2 : n_frames));
-#define HFZ_LAUNCH_ENCODE(F, B)                                                                  \
-  hipLaunchKernelGGL((encode_kernel<F, B>), grid, dim3(64), 0, as_stream(stream), (uint32_t)K,  \
-                     d_raw, total, frame_bytes, n_frames, d_code, shared_code ? 0u : 1u,         \
-                     d_stream_end, d_comp_off, d_comp_size, d_comp, comp_cap)
-  if (pair && wide) HFZ_LAUNCH_ENCODE(2, 64);
-  else if (pair) HFZ_LAUNCH_ENCODE(2, 32);
-  else if (wide) HFZ_LAUNCH_ENCODE(1, 64);
-  else HFZ_LAUNCH_ENCODE(1, 32);
+  const uint32_t threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
+  // the rings of a parts launch: 8 KiB per wave of dynamic LDS (beyond the 64 KiB a
+  // launch may ask for by default when all eight waves are used)
+  const size_t ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
+#define HFZ_LAUNCH_ENCODE(F, B, P)                                                               \
+  do {                                                                                           \
+    if (ring_bytes > (48u << 10)) {                                                              \
+      hipError_t e_ = hipFuncSetAttribute((const void*)&encode_kernel<F, B, P>,                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                          (int)ring_bytes);                                      \
+      if (e_ != hipSuccess) return e_;                                                           \
+    }                                                                                            \
+    hipLaunchKernelGGL((encode_kernel<F, B, P>), grid, dim3(threads), ring_bytes,                \
+                       as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames,      \
+                       d_code, shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size,     \
+                       d_comp, comp_cap, log2_parts);                                            \
+  } while (0)
+  if (log2_parts && wide) HFZ_LAUNCH_ENCODE(1, 64, true);
+  else if (log2_parts) HFZ_LAUNCH_ENCODE(1, 32, true);
+  else if (pair && wide) HFZ_LAUNCH_ENCODE(2, 64, false);
+  else if (pair) HFZ_LAUNCH_ENCODE(2, 32, false);
+  else if (wide) HFZ_LAUNCH_ENCODE(1, 64, false);
+  else HFZ_LAUNCH_ENCODE(1, 32, false);
 #undef HFZ_LAUNCH_ENCODE
   return hipGetLastError();
 }

@@ -298,6 +298,19 @@ int hfz_set_frames_per_wave(int n);
 int hfz_set_encoder_block(int bytes);
 
 /*
+ * Threads per stream in the encoder.  The reference encodes stream after
+ * stream, one symbol at a time (codec/huffman.cpp:825-843); one lane per
+ * stream leaves most of the chip idle when a batch has few frames (a single
+ * frame is one wavefront).  With n > 1 every stream is cut into n parts (a
+ * power of two, at most 512 / K and 64) that are encoded by n threads at once
+ * into the same bytes.  n = 0 (default) picks by batch size: as many parts as
+ * it takes to occupy the chip, none for large batches; 1 = never; other values
+ * are rounded down to what K allows.  Output is identical.  Process-wide; no
+ * counterpart in the reference.
+ */
+int hfz_set_encoder_parts(int n);
+
+/*
  * How the one-frame-per-wave decoder with the 11-bit table writes its output:
  * mode = 1, every lane stores the blocks of its own stream, two 32-byte blocks
  * at a time (best for long streams); mode = 2, neighbouring lanes store each

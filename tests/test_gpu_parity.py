@@ -125,6 +125,40 @@ def test_encoder_block_sizes(torch_cuda):
         hfz.set_encoder_block(0)
 
 
+@pytest.mark.parametrize("parts", [2, 4, 16, 64])
+def test_encoder_parts_per_stream(torch_cuda, parts):
+    # several threads per stream (chosen automatically for batches of few frames,
+    # which includes every single-frame call above): force part counts over every
+    # reference case, odd stream counts, slices shorter than the part count, and
+    # batches, with both block sizes; frames must equal the oracle's byte for byte
+    torch = torch_cuda
+    hfz.set_encoder_parts(parts)
+    try:
+        for nbytes in (32, 64):
+            hfz.set_encoder_block(nbytes)
+            for name in CASE_FILES:
+                raw = load_input(name)
+                for K in tuple(KS) + (3, 7, 24, 40, 48, 63):
+                    assert hfz.compress(K, raw) == oracle.compress(K, raw), (parts, nbytes, name, K)
+        hfz.set_encoder_block(0)
+        for i, raw in enumerate(many_random()):
+            for K in (1, 2, 5, 32, 64):
+                assert hfz.compress(K, raw) == oracle.compress(K, raw), (parts, i, K)
+        for K, total, frame in ((64, (2 << 20) + 77, 256 << 10), (4, 1000003, 100 << 10), (33, 5000, 100),
+                                (8, 3 << 20, 1 << 20), (1, 70001, 70001)):
+            data = hfz.generate(geometric_cdf(), 11 + K, total)
+            host = data.cpu().numpy().tobytes()
+            codec = hfz.BatchCodec(K, total, frame)
+            batch = codec.compress(data)
+            torch.cuda.synchronize()
+            assert int(codec.status.abs().sum().item()) == 0
+            for f in range(codec.n_frames):
+                assert batch.frame_bytes_host(f) == oracle.compress(K, host[f * frame:(f + 1) * frame]), (parts, K, f)
+    finally:
+        hfz.set_encoder_parts(0)
+        hfz.set_encoder_block(0)
+
+
 def test_other_stream_counts(torch_cuda):
     # the AVX-512 paths of the reference also run K = 24, 40, 48
     raw = load_input("long_random.bin")

@@ -18,6 +18,8 @@ def child(lib, cfgs):
         hfz.set_encoder_block(int(os.environ["HFZ_ENCBLK"]))
     if os.environ.get("HFZ_STORE"):
         hfz.set_decoder_store(int(os.environ["HFZ_STORE"]))
+    if os.environ.get("HFZ_PARTS"):
+        hfz.set_encoder_parts(int(os.environ["HFZ_PARTS"]))
     if os.environ.get("HFZ_BITS"):
         hfz.set_decoder_table_bits(int(os.environ["HFZ_BITS"]))
     for cfg in cfgs:
