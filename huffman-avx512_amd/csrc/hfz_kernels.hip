@@ -2255,7 +2255,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   if (shared_code && frame_bytes <= kSharedMaxFrame) {
     // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
-    // LDS, three workgroups (nine frames) per CU and no escape entries.  Pays
+    // LDS, three workgroups (nine frames) per CU and no sibling entries.  Pays
     // off while building a table is a visible part of a frame's work; larger
     // frames go through the per-frame kernels below, which are faster there
     // (one-wave workgroups pack the CUs better) and decode any frame.
@@ -2267,7 +2267,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     return hipGetLastError();
   }
   // 12-bit table (28 KiB of LDS, 5 frames per CU) while that holds every frame
-  // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose escape test
+  // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose 12th-bit pick
   // costs less than the extra resident waves return.
   const int cus = device_cus();
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);

@@ -267,14 +267,14 @@ int hfz_timing_read(hfz_batch_timing* out);
 /*
  * The decoder has two builds of its lookup table (the reference has one,
  * Decoder2x, codec/huffman.cpp:634-704): 12 index bits (16 KiB of LDS per
- * frame, no escape entries) and 11 index bits (8 KiB, more frames resident per
+ * frame, every code resolved by the index) and 11 index bits (8 KiB, more frames resident per
  * CU).  bits = 0 (default) picks by the number of frames in the call; 11 or 12
  * forces one, for tests and tuning.  HFZ_DECODER_TABLE_FREE selects a third
  * build that uses no lookup table at all: code lengths by comparing the window
  * with the first code of each length, symbols by indexing the canonical symbol
  * list, one symbol per step (the method of the reference's permute decoder,
  * codec/huffman.cpp:1697-1756, 1892-1940); it is never chosen automatically (it
- * is 2-3 times slower than the table builds on this machine) and exists for
+ * is 3-4 times slower than the table builds on this machine) and exists for
  * comparison.  Decoded bytes are identical.  Process-wide.
  */
 #define HFZ_DECODER_TABLE_FREE (-1)

@@ -59,7 +59,7 @@ def test_many_random(torch_cuda):
 @pytest.mark.parametrize("bits", [11, 12, hfz.DECODER_TABLE_FREE])
 def test_both_decoder_table_builds(torch_cuda, bits):
     # the decoder picks its lookup-table build by frame count; force each one over
-    # every reference case (12-bit codes take the escape entries of the 11-bit build),
+    # every reference case (12-bit codes take the two-symbol sibling entries of the 11-bit build),
     # and the table-free build (first-code compare chain + canonical symbol list)
     torch = torch_cuda
     hfz.set_decoder_table_bits(bits)
