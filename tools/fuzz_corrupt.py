@@ -22,6 +22,7 @@ while time.time() - t0 < budget:
     total = frame_bytes * n_frames - int(rng.integers(0, frame_bytes))
     hfz.set_decoder_table_bits(int(rng.choice([0, 11, 12])))
     hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
+    hfz.set_decoder_store(int(rng.choice([0, 1, 2])))
     raw = hfz.generate(sources[int(rng.integers(0, len(sources)))], seed * 7919 + case, total)
     codec = hfz.BatchCodec(K, total, frame_bytes, strided=bool(rng.integers(0, 2)))
     batch = codec.compress(raw)

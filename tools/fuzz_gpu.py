@@ -48,6 +48,8 @@ while time.time() - t0 < budget:
     strided = bool(rng.integers(0, 2))
     bits, fpw, blk = int(rng.choice([0, 11, 12])), int(rng.choice([0, 1, 2])), int(rng.choice([0, 32, 64]))
     hfz.set_decoder_table_bits(bits)
+    hfz.set_encoder_parts(int(rng.choice([0, 0, 1, 2, 8, 64])))
+    hfz.set_decoder_store(int(rng.choice([0, 1, 2])))
     hfz.set_frames_per_wave(fpw)
     hfz.set_encoder_block(blk)
     raw = hfz.generate(random_source(), seed * 100003 + case, total) if total else torch.empty(
