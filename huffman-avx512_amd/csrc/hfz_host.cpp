@@ -432,7 +432,7 @@ int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_
   HFZ_HIP(mark(0, st));
   HFZ_HIP(mark(1, st));  // the input pass was hfz_count_batch_dev
   if (count_kernel_fits(K, frame_bytes)) {
-    HFZ_HIP(launch_code_sizes(K, nullptr, (const uint32_t*)(ws + w.counts), nf, nullptr, code, true,
+    HFZ_HIP(launch_code_sizes(K, (const uint32_t*)(ws + w.hist), (const uint32_t*)(ws + w.counts), nf, nullptr, code, true,
                               d_send, d_csize, stream));
     HFZ_HIP(mark(2, st));
   } else {

@@ -824,19 +824,34 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
 
   // frame histogram: thread t sums row t, starting at a different word per
   // thread so that the 64 lanes read 32 different banks
-  {
-    uint32_t sum = 0;
+  uint32_t sum = 0;
 #pragma unroll 8
-    for (uint32_t c = 0; c < 32; ++c) {
-      const uint32_t w = cnt[tid * 32 + ((c + tid) & 31)];
-      sum += packed ? (w & 0xffff) + (w >> 16) : w;
-    }
-    if (hist_out) hist_out[f * 256 + tid] = sum;
+  for (uint32_t c = 0; c < 32; ++c) {
+    const uint32_t w = cnt[tid * 32 + ((c + tid) & 31)];
+    sum += packed ? (w & 0xffff) + (w >> 16) : w;
   }
+  if (hist_out) hist_out[f * 256 + tid] = sum;
   if (counts_out) {
+    // Only the rows of byte values that occur go to memory, packed in ascending
+    // order of the value (a fifth of the rows on the reference's biased source);
+    // code_sizes_kernel finds out which they are from the histogram.
+    const bool occurs = sum != 0;
+    const uint64_t bal = __ballot(occurs);
+    if (lane == 0) part_bits[wave][0] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t at = (uint32_t)__popcll(bal & ((1ull << lane) - 1)), n_rows = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCntThreads / 64; ++w) {
+      const uint32_t c = part_bits[w][0];
+      if (w < wave) at += c;
+      n_rows += c;
+    }
+    uint8_t* const row_of = (uint8_t*)lens4;  // 256 bytes
+    if (occurs) row_of[at] = (uint8_t)tid;
+    __syncthreads();
     uint4* dst = (uint4*)(counts_out + f * (256 * 32));
     const uint4* src = (const uint4*)cnt;
-    for (uint32_t i = tid; i < 256 * 32 / 4; i += kCntThreads) dst[i] = src[i];
+    for (uint32_t i = tid; i < 8 * n_rows; i += kCntThreads) dst[i] = src[8 * (uint32_t)row_of[i >> 3] + (i & 7)];
     return;
   }
   if (wave == 0) {
@@ -887,8 +902,9 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
 
 // Second half of the counting path, one wave per frame: the frame's code from
 // its histogram (build_code), then the coded size of every stream from the
-// per-stream counts count_kernel left in memory (same layout as its LDS array).
-// Lane l walks the rows of parity l / 32 and owns counter word l % 32.
+// per-stream counts count_kernel left in memory: the rows of its LDS array for
+// the byte values that occur (nonzero histogram bins), packed in ascending order.
+// Lane l walks the packed rows of parity l / 32 and owns counter word l % 32.
 // given != null: no code is built; the sizes are those under given[f * given_step].
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ counts,
@@ -898,15 +914,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
                                                         uint32_t* __restrict__ stream_end,
                                                         uint32_t* __restrict__ csize) {
   __shared__ uint32_t lens[256];
+  __shared__ uint32_t row_len[256];  // code length of the byte value of packed row j
   __shared__ uint32_t sums[64];
   const uint64_t f = blockIdx.x;
   const uint32_t lane = threadIdx.x;
-  const uint32_t* rows = counts + f * (256 * 32) + lane;  // word (row l/32, column l%32)
-  // the counters do not depend on the code: start fetching them now
+  const uint32_t* rows = counts + f * (256 * 32) + lane;  // word (packed row l/32, column l%32)
+  // the counters do not depend on the code: start fetching them now (rows past
+  // the last packed one hold stale data and are skipped below)
   constexpr uint32_t kAhead = 8;
   uint32_t nxt[kAhead];
 #pragma unroll
   for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * i];
+  // which byte values occur: lane l looks at values 4l .. 4l+3
+  const uint4 h4 = *(const uint4*)(hist + f * 256 + 4 * lane);
+  const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
+  uint32_t nz = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nz += hv[j] != 0;
+  const uint32_t incl = wave_inclusive_scan(nz, lane);
+  const uint32_t n_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63, 64));
   uint32_t hdr_len;
   if (given) {
     const FrameCode& fc = given[f * given_step];
@@ -919,27 +945,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   }
   sums[lane] = 0;
   wave_sync();
+  {
+    uint32_t at = incl - nz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (hv[j] != 0) row_len[at++] = lens[4 * lane + j];
+  }
+  wave_sync();
   if (!given) hdr_len = code[f].hdr_len;  // written by lane 0 of this wave inside build_code
   const bool packed = K > 32;
   const uint32_t reps = packed ? 1 : 32 / K;
   const uint32_t col = lane & 31, par = lane >> 5;
   uint32_t acc_lo = 0, acc_hi = 0;
-  for (uint32_t g = 0; g < 128 / kAhead; ++g) {
+  const uint32_t n_groups = ((n_rows + 1) / 2 + kAhead - 1) / kAhead;  // kAhead row pairs each
+  for (uint32_t g = 0; g < n_groups; ++g) {
     uint32_t cur[kAhead];
 #pragma unroll
     for (uint32_t i = 0; i < kAhead; ++i) cur[i] = nxt[i];
-    if (g + 1 < 128 / kAhead) {
+    if (g + 1 < n_groups) {
 #pragma unroll
       for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * (kAhead * (g + 1) + i)];
     }
 #pragma unroll
     for (uint32_t i = 0; i < kAhead; ++i) {
-      const uint32_t len = lens[2 * (kAhead * g + i) + par];
+      const uint32_t r = 2 * (kAhead * g + i) + par;
+      const uint32_t len = r < n_rows ? row_len[r] : 0;
+      const uint32_t c = r < n_rows ? cur[i] : 0;
       if (packed) {
-        acc_lo += (cur[i] & 0xffff) * len;
-        acc_hi += (cur[i] >> 16) * len;
+        acc_lo += (c & 0xffff) * len;
+        acc_hi += (c >> 16) * len;
       } else {
-        acc_lo += cur[i] * len;
+        acc_lo += c * len;
       }
     }
   }
@@ -952,9 +988,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   wave_sync();
   uint32_t bytes = 0;
   if (lane < K) bytes = (sums[lane] + 7) / 8 + kSlop;
-  const uint32_t incl = wave_inclusive_scan(bytes, lane);
-  if (lane < K) stream_end[f * 64 + lane] = incl;
-  if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl;
+  const uint32_t incl_b = wave_inclusive_scan(bytes, lane);
+  if (lane < K) stream_end[f * 64 + lane] = incl_b;
+  if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl_b;
 }
 
 // Sum of the per-frame histograms of a batch, 64-bit: total[c] = sum over f of hist[f][c].
