@@ -159,6 +159,41 @@ def test_encoder_parts_per_stream(torch_cuda, parts):
         hfz.set_encoder_block(0)
 
 
+def test_host_buffer_calls_from_several_threads(torch_cuda):
+    # hfz_compress / hfz_decompress keep their device and pinned buffers in a pool;
+    # concurrent callers must each get buffers of their own (ctypes drops the GIL
+    # during the calls), whatever sizes they ask for and in whatever order
+    import threading
+    inputs = [load_input(n) for n in ("lorem.bin", "long_random.bin", "biased_100k.bin", "hello.bin",
+                                      "long_codes.bin", "equal_counts.bin")]
+    want = {(K, i): oracle.compress(K, raw) for i, raw in enumerate(inputs) for K in (4, 32, 64)}
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for i, raw in enumerate(inputs):
+                    K = (4, 32, 64)[(t + rep + i) % 3]
+                    comp = hfz.compress(K, raw)
+                    if comp != want[(K, i)] or hfz.decompress(K, comp) != raw:
+                        errors.append((t, rep, i, K))
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    # a large frame (beyond the staged-copy sizes) after the small ones, then small again
+    big = hfz.generate(geometric_cdf(), 99, 9 << 20).cpu().numpy().tobytes()
+    comp = hfz.compress(64, big)
+    assert hfz.decompress(64, comp) == big
+    assert comp[:64] == oracle.compress(64, big)[:64]
+    assert hfz.decompress(32, hfz.compress(32, inputs[0])) == inputs[0]
+
+
 def test_other_stream_counts(torch_cuda):
     # the AVX-512 paths of the reference also run K = 24, 40, 48
     raw = load_input("long_random.bin")
