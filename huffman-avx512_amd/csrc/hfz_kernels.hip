@@ -1520,7 +1520,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   const uint32_t k = kF == 1 ? lane : lane & 31;  // stream index within the frame
   uint32_t* const iring = ringmem + wave * 64 * (kDecInDw + kDecOutDw);
   uint32_t* const obuf_all = iring + 64 * kDecInDw;
-  // scratch that is only live while a table is built (on the first wave's input rings)
+  // scratch that is only live while a table is built (on the first wave's input
+  // rings): the length of the first code under every (reversed) table index
   uint8_t* const l1tab = (uint8_t*)ringmem;
   static_assert(sizeof(uint32_t) * 64 * kDecInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
   static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
@@ -1668,13 +1669,19 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     }
     STAMP(0);  // header
 
-    // single-symbol entries, one code-length class at a time.  e runs over the
-    // top kDecTabBits bits of the left-aligned 12-bit code space; the entry is
-    // stored at the bit-reversed index (the reader looks codes up bit-reversed)
+    // Single-symbol entries.  The reader looks codes up bit-reversed, so entry r
+    // of the table belongs to the code prefix whose reversed bits are r.  Every
+    // thread fills the entries r = tid, tid + threads, ...: neighbouring lanes
+    // write neighbouring words (filling class by class in code order instead puts
+    // a wave's 64 stores on one or two banks, because codes that are neighbours in
+    // code order differ in their LAST bits, the top bits of r).  The length of the
+    // code under a prefix is the number of lengths whose codes end at or below it
+    // (the first codes ascend with the length); first code and first symbol index
+    // of every length sit in a 13-word list next to the scratch.
     uint32_t* const ptab = tab + (pass << kDecTabBits);
     constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
     static_assert(kTabShift <= 1, "sibling entries cover one bit");
-#define HFZ_TIX(e) (__builtin_bitreverse32(e) >> (32 - (kTableFree ? 1 : kDecTabBits)))
+    uint32_t* const cls = ringmem + 1024;  // behind l1tab (at most 4096 bytes)
     if (kTableFree) {
 #pragma unroll
       for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = __builtin_amdgcn_readfirstlane(fcode[l + 1]);
@@ -1683,47 +1690,47 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         if (lane == (uint32_t)L) tab[L] = fcode[L] | (soff[L] << 16);
       uint8_t* const list = (uint8_t*)(tab + 16);
       for (uint32_t i = lane; i < nsym; i += 64) list[i] = syms[i];
-    } else if (kF == 1 || p_err == HFZ_OK) {
-      // with sibling entries in the table, a lone symbol sits in bytes 2 and 3
-      constexpr uint32_t kDup = kTabShift ? 0x0101u : 0x0001u;
+    } else {
 #pragma unroll
-      for (uint32_t L = 0; L <= kDecTabBits; ++L) {
-        if (cnt[L] == 0) continue;
-        const uint32_t lo = fcode[L] >> kTabShift, hi = fcode[L + 1] >> kTabShift;
+      for (int L = 0; L <= kMaxCodeLen; ++L)
+        if (tid == (uint32_t)L) cls[L] = fcode[L] | (soff[L] << 16);
+    }
+    HFZ_BARRIER();
+    if (!kTableFree && (kF == 1 || p_err == HFZ_OK)) {
 #pragma unroll 4
-        for (uint32_t e = lo + tid; e < hi; e += 64 * kWaves) {
-          const uint32_t j = soff[L] + ((e - lo) >> (kDecTabBits - L));
-          ptab[HFZ_TIX(e)] = L | (8u << 8) | (((uint32_t)syms[j] * kDup) << 16);
-          l1tab[e] = (uint8_t)L;
-        }
-      }
-      if (kTabShift) {  // sibling pairs of 12-bit codes (their count is even: the code is complete)
-        const uint32_t lo = fcode[kMaxCodeLen] >> 1;
-        for (uint32_t e = lo + tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
-          const uint32_t j = soff[kMaxCodeLen] + 2 * (e - lo);
-          ptab[HFZ_TIX(e)] = (uint32_t)kMaxCodeLen | (8u << 8) | ((uint32_t)syms[j] << 16) |
-                             ((uint32_t)syms[j + 1] << 24);
-          l1tab[e] = (uint8_t)kMaxCodeLen;
-        }
+      for (uint32_t r = tid; r < (1u << kDecTabBits); r += 64 * kWaves) {
+        const uint32_t c12 = (__builtin_bitreverse32(r) >> (32 - (kTableFree ? 1 : kDecTabBits))) << kTabShift;
+        uint32_t L = 0;
+#pragma unroll
+        for (int l = 0; l < kMaxCodeLen; ++l) L += c12 >= fcode[l + 1] ? 1u : 0u;
+        const uint32_t cl = cls[L];
+        const uint32_t d = c12 - (cl & 0xffffu);
+        // 11-bit table: a 12-bit code shares its entry with its sibling (their
+        // number is even: the code is complete), both symbols in the entry; a
+        // lone symbol sits in bytes 2 and 3 alike
+        const bool sibling = kTabShift && L == (uint32_t)kMaxCodeLen;
+        const uint32_t j = (cl >> 16) + (sibling ? d : d >> ((uint32_t)kMaxCodeLen - L));
+        const uint32_t s0 = syms[j];
+        const uint32_t s1 = sibling ? (uint32_t)syms[j + 1] : (kTabShift ? s0 : 0u);
+        ptab[r] = L | (8u << 8) | (s0 << 16) | (s1 << 24);
+        l1tab[r] = (uint8_t)L;
       }
     }
     HFZ_BARRIER();
-    // second symbol where both codes fit in the index bits.  Byte 2 of an entry
-    // and l1tab never change in this pass, so reading another lane's entry while
-    // it is being rewritten is safe.
+    // second symbol where both codes fit in the index bits: dropping the first
+    // code from a prefix is a right shift of its reversed index.  Byte 2 of an
+    // entry and l1tab never change in this pass, so reading another lane's entry
+    // while it is being rewritten is safe.
     if (!kTableFree && (kF == 1 || p_err == HFZ_OK)) {
 #pragma unroll 8
-      for (uint32_t e = tid; e < (1u << kDecTabBits); e += 64 * kWaves) {
-        const uint32_t L1 = l1tab[e];
-        const uint32_t rem = (e << L1) & ((1u << kDecTabBits) - 1);
-        const uint32_t L2 = l1tab[rem];
-        if (L1 + L2 <= kDecTabBits) {
-          uint32_t* const pe = ptab + HFZ_TIX(e);
-          *pe = (L1 + L2) | (16u << 8) | (*pe & 0xff0000) | ((ptab[HFZ_TIX(rem)] & 0xff0000) << 8);
-        }
+      for (uint32_t r = tid; r < (1u << kDecTabBits); r += 64 * kWaves) {
+        const uint32_t L1 = l1tab[r];
+        const uint32_t rr = r >> L1;
+        const uint32_t L2 = l1tab[rr];
+        if (L1 + L2 <= kDecTabBits)
+          ptab[r] = (L1 + L2) | (16u << 8) | (ptab[r] & 0xff0000) | ((ptab[rr] & 0xff0000) << 8);
       }
     }
-#undef HFZ_TIX
     HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
     STAMP(1);  // table
   }
