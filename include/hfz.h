@@ -127,6 +127,13 @@ int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_code
  * hfz_build_codes_dev on 16, every other u32/i32 array on 4 (hipMalloc and
  * torch allocations satisfy all of these); a misaligned pointer is refused
  * with HFZ_E_ARG.  d_raw and d_comp may have any alignment.
+ *
+ * Workspace: hfz_workspace_bytes(K, n_frames) is the worst case for any frame
+ * size, about 35 KiB per frame whatever K is (histogram, code record, stream
+ * offsets, and 32 KiB for the per-stream counters of the byte values that occur;
+ * large slices and the shared-code encoder with a given code do not touch the
+ * counters, but the size is checked all the same).  For small frames it exceeds
+ * the raw data; allocate it once and reuse it.
  */
 size_t hfz_batch_frames(size_t total, size_t frame_bytes);
 size_t hfz_workspace_bytes(int K, size_t n_frames);
