@@ -1836,13 +1836,13 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   } while (0)
   HFZ_REFILL();
 
-  // output: decoded bytes collect in obuf (sh = 8 * their number, < 32 between
+  // output: decoded bytes collect in ocur (sh = 8 * their number, < 32 between
   // pairs); wp is the output offset of the dword being filled.  That
   // dword is written to the ring after every pair and simply rewritten until it
   // is complete.  nfb = next 32-byte block to leave the ring.  A full block is
   // read into sb[] at the end of the round that completed it and stored to
   // memory at the end of the next one, when the LDS reads have long returned.
-  uint64_t obuf = 0;
+  uint32_t ocur = 0;
   uint32_t sh = 8 * (out_lo & 3);  // bytes below the slice start in the first dword
   uint32_t wp = out_lo & ~3u;
   // wa = 256 * (ring row of the dword at wp), running on without wrapping: one
@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   ((!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen)                                         \
        ? __builtin_amdgcn_ubfe((e_), ((((t_) >> 10) & (w_)) | 16), (w_))                        \
        : (e_) >> 16)
-  // two lookups, their symbols appended to obuf, the finished dword written out,
+  // two lookups, their symbols appended to ocur, the finished dword written out,
   // the bit reader moved on
 #define HFZ_PAIR()                                                           \
   do {                                                                       \
@@ -1885,11 +1885,12 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     const uint32_t w1_ = e1_ >> 8, w2_ = e2_ >> 8;                           \
     const uint32_t y1_ = HFZ_SYMS(e1_, t1_, w1_);                            \
     const uint32_t y2_ = HFZ_SYMS(e2_, t2_, w2_);                            \
-    obuf |= (uint64_t)(y1_ | (y2_ << (w1_ & 31))) << sh;                     \
+    const uint64_t sp_ = (uint64_t)(y1_ | (y2_ << (w1_ & 31))) << sh;        \
+    const uint32_t lo_ = ocur | (uint32_t)sp_;                               \
     sh += w1_ + w2_;                                                         \
-    *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;                \
+    *(uint32_t*)(ocol + (wa & kOutRowMask)) = lo_;                           \
     const uint32_t f_ = sh & 32;                                             \
-    obuf >>= f_;                                                             \
+    ocur = (uint32_t)(((sp_ & 0xffffffff00000000ull) | lo_) >> f_);          \
     wa += f_ << 3;                                                           \
     sh &= 31;                                                                \
     HFZ_REFILL();                                                            \
@@ -2035,7 +2036,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   if (kStore != 2 && sb_full) HFZ_STORE_BLOCK();
   if (kPair64 && sc_full) HFZ_STORE_ODD_BLOCK();
   // the last partial dword, then what is left in the ring: up to two blocks
-  *(uint32_t*)(ocol + (wa & kOutRowMask)) = (uint32_t)obuf;
+  *(uint32_t*)(ocol + (wa & kOutRowMask)) = ocur;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (nfb < out_hi) {
