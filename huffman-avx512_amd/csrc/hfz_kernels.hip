@@ -1239,50 +1239,56 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
   }
 
   uint8_t* const ocol = (uint8_t*)(oring + (kParts ? (tid >> 6) * 64 * kEncRingDw : 0u) + lane);  // row r of this lane: ocol + 256 * r
-  // bit writer: acc holds nb (< 32 between pairs) pending bits MSB first.  The
-  // dword being filled sits at output offset wp - 4; ua is 256 times its ring
-  // row, not wrapped (wp = wp0 - (ua - ua0) / 64).  If the stream does not end
-  // on a dword boundary the bytes above its end count as already written.
-  uint64_t acc = 0;
-  uint32_t nb = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
+  // bit writer: wcur holds the pending bits of the dword being filled, MSB first.
+  // S counts the stream's bits: its low five bits are the number of pending bits
+  // and bits 5..9 the ring row of the dword being filled (one row per finished
+  // dword), so (S << 3) & kRowMask is that row's byte offset.  Whole table
+  // entries are added to S: bits 4..19 of an entry are zero, so the low twenty
+  // bits of S stay exact while the code bits pile up above them; once per input
+  // block S is cut back to those twenty bits and wp, the output offset just above
+  // the dword being filled, is brought up to date.  If the stream does not end on
+  // a dword boundary the bytes above its end count as already written.
+  uint32_t wcur = 0;
+  uint32_t nb0 = (r_hi & 3) ? 8 * (4 - (r_hi & 3)) : 0;
   if (kParts && lead_n) {
-    acc = ((uint64_t)lead << (64 - lead_n)) >> nb;
-    nb += lead_n;
+    wcur = (lead << (32 - lead_n)) >> nb0;  // nb0 + lead_n <= 31
+    nb0 += lead_n;
   }
   const uint32_t wp0 = (r_hi + 3) & ~3u;
-  const uint32_t ua0 = ((~((wp0 - 4) >> 2)) & (kEncRingDw - 1)) << 8;
-  uint32_t ua = ua0;
+  constexpr uint32_t kRowMask = (kEncRingDw - 1) << 8;
+  uint32_t S = (((~((wp0 - 4) >> 2)) & (kEncRingDw - 1)) << 5) + nb0;
+  uint32_t s_seen = S;  // S when wp was last brought up to date
+  uint32_t wp = wp0;
   uint32_t nf = (r_hi - 1) & ~(kEncOutBlk - 1);  // next block to store (descending)
   const uint32_t nf_last = r_lo & ~(kEncOutBlk - 1);
   bool nf_live = r_lo < r_hi;  // always true for a whole stream (it has its 8 bytes of slop)
-  constexpr uint32_t kRowMask = (kEncRingDw - 1) << 8;
 
-  // Merges two table entries and appends them.  The current dword is written
-  // every time (it is simply rewritten until it is complete); ua, acc and nb
-  // advance only when 32 bits have been collected.  Bits 4..19 of an entry are
-  // zero, so the low bits of e0 + e1 + nb are the new bit count.
+  // Appends the left-aligned code bits v_ (at most 24) and moves on by the entries
+  // sum_: the current dword is written every time (it is simply rewritten until it
+  // is complete); when bit 5 of S flips the dword is complete and the bits that
+  // did not fit become the next one.
+#define HFZ_PUT(v_, sum_)                                                     \
+  do {                                                                        \
+    wcur |= (v_) >> (S & 31);                                                  \
+    *(uint32_t*)(ocol + ((S << 3) & kRowMask)) = wcur;                         \
+    const uint32_t sn_ = S + (sum_);                                          \
+    const uint32_t full_ = (sn_ ^ S) & 32;                                    \
+    wcur = (uint32_t)((((uint64_t)__builtin_amdgcn_alignbit((v_), 0u, S) << 32) | wcur) >> full_); \
+    S = sn_;                                                                  \
+  } while (0)
+  // Two table entries merged: the second code moves down by the length of the
+  // first; what the lengths leave in bits 0..3 is cut off.
 #define HFZ_PAIR(b0, b1)                                                      \
   do {                                                                        \
     const uint32_t e0_ = enc[(b0)], e1_ = enc[(b1)];                          \
-    const uint32_t pair_ = (e0_ & 0xfff00000u) | ((e1_ & 0xfff00000u) >> (e0_ & 31)); \
-    acc |= ((uint64_t)pair_ << 32) >> nb;                                     \
-    *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);             \
-    const uint32_t nbs_ = e0_ + e1_ + nb;                                     \
-    const uint32_t full_ = nbs_ & 32;                                         \
-    ua += full_ << 3;                                                         \
-    acc <<= full_;                                                            \
-    nb = nbs_ & 31;                                                           \
+    const uint32_t pair_ = (e0_ | (e1_ >> (e0_ & 31))) & 0xffffff00u;         \
+    HFZ_PUT(pair_, e0_ + e1_);                                                \
   } while (0)
 #define HFZ_ONE(b0)                                                           \
   do {                                                                        \
     const uint32_t e0_ = enc[(b0)];                                           \
-    acc |= ((uint64_t)(e0_ & 0xfff00000u) << 32) >> nb;                       \
-    *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);             \
-    const uint32_t nbs_ = e0_ + nb;                                           \
-    const uint32_t full_ = nbs_ & 32;                                         \
-    ua += full_ << 3;                                                         \
-    acc <<= full_;                                                            \
-    nb = nbs_ & 31;                                                           \
+    const uint32_t one_ = e0_ & 0xfff00000u;                                  \
+    HFZ_PUT(one_, e0_);                                                       \
   } while (0)
   // stores the ring block holding output offsets [blk, blk+kEncOutBlk); only bytes of
   // this stream's region [r_lo, r_hi) are written
@@ -1352,7 +1358,9 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
         }
       }
       // store the blocks that are complete (everything at or above wp is final)
-      const uint32_t wp = wp0 - ((ua - ua0) >> 6);
+      S &= 0xfffffu;
+      wp -= (((S >> 5) - (s_seen >> 5)) & 0x7fffu) << 2;
+      s_seen = S;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         if (nf_live && wp <= nf) {
@@ -1366,24 +1374,17 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
 #undef HFZ_LOAD_GROUP
   STAMP(3);  // main loop
   // end of stream: pad to a byte, then the 8 zero bytes of slop
-  // (codec/huffman.cpp:770), then the last partial dword
-  nb = (nb + 7) & ~7u;
-#pragma unroll
-  for (int z = 0; z < 3; ++z) {
-    if (nb >= 32) {
-      *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);
-      ua += 256;
-      acc <<= 32;
-      nb -= 32;
-    }
-    if (z < 2) nb += 32;
-  }
-  if (nb > 0) *(uint32_t*)(ocol + (ua & kRowMask)) = (uint32_t)(acc >> 32);
+  // (codec/huffman.cpp:770): the dword being filled and below it one zero dword,
+  // or two if the padded dword is not empty
+  *(uint32_t*)(ocol + ((S << 3) & kRowMask)) = wcur;
+  *(uint32_t*)(ocol + (((S + 32) << 3) & kRowMask)) = 0;
+  if (S & 31) *(uint32_t*)(ocol + (((S + 64) << 3) & kRowMask)) = 0;
   while (nf_live) {
     HFZ_STORE_BLOCK(nf);
     if (nf == nf_last) nf_live = false;
     nf -= kEncOutBlk;
   }
+#undef HFZ_PUT
 #undef HFZ_PAIR
 #undef HFZ_ONE
 #undef HFZ_STORE_BLOCK
