@@ -28,18 +28,22 @@ int hip_fail(hipError_t e) {
   } while (0)
 
 // Per-thread event sets for hfz_timing_*: while timing is on, every `every`-th
-// batch call of a kind (the first included) takes a fresh set and records an
-// event before and after each of its kernels; hfz_timing_read averages over all
-// sets taken since the last read.  Events between kernels keep one kernel's
-// tail from overlapping the next one's start, which costs a few percent of a
-// short batch: sampling keeps the measurement and most of the overlap.
-constexpr int kEncEvents = 6, kDecEvents = 2, kCntEvents = 2, kMaxTimedCalls = 512;
+// batch call of a kind (the first included) takes a fresh set, and each of its
+// kernels is launched with a pair of events that receive the kernel's own begin
+// and end timestamps (KernelSpan); hfz_timing_read averages over all sets taken
+// since the last read.  Timed launches keep one kernel's tail from overlapping
+// the next one's start, which costs a few percent of a short batch: sampling
+// keeps the measurement and most of the overlap.
+constexpr int kEncSpans = 5;  // hist, table, sizes, place, encode
+constexpr int kEncEvents = 2 * kEncSpans, kDecEvents = 2, kCntEvents = 2, kMaxTimedCalls = 512;
 struct Timing {
   int every = 0;                          // 0 = off
   std::vector<hipEvent_t> enc, dec, cnt;  // kEncEvents / kDecEvents / kCntEvents per timed call
+  std::vector<uint8_t> enc_used;          // per timed compress call: bit i = span i was launched
   size_t enc_calls = 0, dec_calls = 0, cnt_calls = 0;  // timed calls
   size_t enc_seen = 0, dec_seen = 0, cnt_seen = 0;     // all calls while on
   hipEvent_t* cur = nullptr;
+  KernelSpan span_buf;
   void reset_window() {
     enc_calls = dec_calls = cnt_calls = 0;
     enc_seen = dec_seen = cnt_seen = 0;
@@ -52,10 +56,13 @@ struct Timing {
       for (hipEvent_t e : *v) (void)hipEventDestroy(e);
       v->clear();
     }
+    enc_used.clear();
   }
-  hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, size_t& seen, int per_call) {
+  // n_frames == 0: the call launches nothing, so there is nothing to time
+  hipError_t take(std::vector<hipEvent_t>& v, size_t& calls, size_t& seen, int per_call,
+                  size_t n_frames) {
     cur = nullptr;
-    if (every <= 0) return hipSuccess;
+    if (every <= 0 || n_frames == 0) return hipSuccess;
     if (seen++ % (size_t)every != 0 || calls >= (size_t)kMaxTimedCalls) return hipSuccess;
     while (v.size() < (calls + 1) * per_call) {
       hipEvent_t e;
@@ -65,15 +72,27 @@ struct Timing {
     }
     cur = &v[calls * per_call];
     ++calls;
+    if (&v == &enc) {
+      enc_used.resize(calls);
+      enc_used[calls - 1] = 0;
+    }
     return hipSuccess;
+  }
+  // The span for kernel i of the call being timed (nullptr: the call is not timed).
+  // The pointer is good until the next call of span().
+  const KernelSpan* span(int i) {
+    if (!cur) return nullptr;
+    span_buf.begin = cur[2 * i];
+    span_buf.end = cur[2 * i + 1];
+    return &span_buf;
+  }
+  const KernelSpan* enc_span(int i) {
+    if (!cur) return nullptr;
+    enc_used[enc_calls - 1] |= (uint8_t)(1u << i);
+    return span(i);
   }
 };
 thread_local Timing g_timing;
-
-hipError_t mark(int i, hipStream_t st) {
-  if (!g_timing.cur) return hipSuccess;
-  return hipEventRecord(g_timing.cur[i], st);
-}
 
 // The kernels read histograms and counters with 16-byte vector loads and carve
 // the workspace on 256-byte boundaries.
@@ -307,13 +326,11 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
   FrameCode* d_code = (FrameCode*)(ws + w.code);
   uint32_t* d_send = (uint32_t*)(ws + w.stream_end);
   uint32_t* d_csize = (uint32_t*)(ws + w.csize);
-  hipStream_t st = (hipStream_t)stream;
   const uint8_t* raw = (const uint8_t*)d_raw;
   const bool shared = d_shared != nullptr;
   const FrameCode* enc_code = shared ? d_shared : d_code;
 
-  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents));
-  HFZ_HIP(mark(0, st));
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents, nf));
   if (count_kernel_fits(K, frame_bytes)) {
     // one pass over the input for the per-stream counts (hist_ms), then code and
     // stream sizes from those (table_ms); sizes_ms reads 0.  With a shared code
@@ -321,27 +338,23 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
     uint32_t* d_counts = (uint32_t*)(ws + w.counts);
     HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, shared ? d_shared : nullptr, shared,
                          shared ? nullptr : d_counts, shared ? nullptr : d_hist, d_send, d_csize,
-                         stream));
-    HFZ_HIP(mark(1, st));
+                         stream, g_timing.enc_span(0)));
     if (!shared)
       HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, nullptr, false, d_send, d_csize,
-                                stream));
-    HFZ_HIP(mark(2, st));
+                                stream, g_timing.enc_span(1)));
   } else {
-    if (!shared) HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
-    HFZ_HIP(mark(1, st));
-    HFZ_HIP(mark(2, st));  // the code is built inside the sizes kernel (table_ms reads 0)
+    // the code is built inside the sizes kernel (table_ms reads 0)
+    if (!shared)
+      HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream, false,
+                               g_timing.enc_span(0)));
     HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, shared ? nullptr : d_hist,
                                 shared ? const_cast<FrameCode*>(d_shared) : d_code, shared, d_send,
-                                d_csize, stream));
+                                d_csize, stream, g_timing.enc_span(2)));
   }
-  HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
-                               d_status, stream));
-  HFZ_HIP(mark(4, st));
+                               d_status, stream, g_timing.enc_span(3)));
   HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, enc_code, shared, d_send, d_comp_off,
-                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream));
-  HFZ_HIP(mark(5, st));
+                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream, g_timing.enc_span(4)));
   g_timing.cur = nullptr;
   return HFZ_OK;
 }
@@ -359,11 +372,10 @@ int decompress_batch(int K, const void* d_comp, size_t comp_bytes, const uint64_
   if (misaligned(d_comp_off, 8) || misaligned(d_comp_size, 4) || misaligned(d_status, 4))
     return HFZ_E_ARG;
   if (frame_bytes > HFZ_MAX_FRAME_BYTES) return HFZ_E_TOO_LARGE;
-  HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, g_timing.dec_seen, kDecEvents));
-  HFZ_HIP(mark(0, (hipStream_t)stream));
+  HFZ_HIP(g_timing.take(g_timing.dec, g_timing.dec_calls, g_timing.dec_seen, kDecEvents, n_frames));
   HFZ_HIP(launch_decode(K, (const uint8_t*)d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames,
-                        shared, (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream));
-  HFZ_HIP(mark(1, (hipStream_t)stream));
+                        shared, (uint8_t*)d_raw, raw_cap, frame_bytes, d_status, stream,
+                        g_timing.span(0)));
   g_timing.cur = nullptr;
   return HFZ_OK;
 }
@@ -392,16 +404,15 @@ int hfz_count_batch_dev(int K, const void* d_raw, size_t total, size_t frame_byt
   uint8_t* ws = (uint8_t*)d_ws;
   uint32_t* d_hist = (uint32_t*)(ws + w.hist);
   const uint8_t* raw = (const uint8_t*)d_raw;
-  hipStream_t st = (hipStream_t)stream;
-  HFZ_HIP(g_timing.take(g_timing.cnt, g_timing.cnt_calls, g_timing.cnt_seen, kCntEvents));
-  HFZ_HIP(mark(0, st));
+  HFZ_HIP(g_timing.take(g_timing.cnt, g_timing.cnt_calls, g_timing.cnt_seen, kCntEvents, nf));
+  // count_ms is the input pass alone; the 256-bin reduction below is not in it
   if (count_kernel_fits(K, frame_bytes)) {
     HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, false, (uint32_t*)(ws + w.counts),
-                         d_hist, (uint32_t*)(ws + w.stream_end), (uint32_t*)(ws + w.csize), stream));
+                         d_hist, (uint32_t*)(ws + w.stream_end), (uint32_t*)(ws + w.csize), stream,
+                         g_timing.span(0)));
   } else {
-    HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream));
+    HFZ_HIP(launch_histogram(raw, total, frame_bytes, nf, d_hist, stream, false, g_timing.span(0)));
   }
-  HFZ_HIP(mark(1, st));  // count_ms is the input pass alone; the 256-bin reduction below is not in it
   g_timing.cur = nullptr;
   HFZ_HIP(launch_hist_total(d_hist, nf, d_hist_total, stream));
   return HFZ_OK;
@@ -427,26 +438,19 @@ int hfz_compress_batch_counted_dev(int K, const void* d_raw, size_t total, size_
   uint32_t* d_csize = (uint32_t*)(ws + w.csize);
   const FrameCode* code = (const FrameCode*)d_code;
   const uint8_t* raw = (const uint8_t*)d_raw;
-  hipStream_t st = (hipStream_t)stream;
-  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents));
-  HFZ_HIP(mark(0, st));
-  HFZ_HIP(mark(1, st));  // the input pass was hfz_count_batch_dev
+  HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents, nf));
+  // the input pass was hfz_count_batch_dev (hist_ms reads 0 here)
   if (count_kernel_fits(K, frame_bytes)) {
     HFZ_HIP(launch_code_sizes(K, (const uint32_t*)(ws + w.hist), (const uint32_t*)(ws + w.counts), nf, nullptr, code, true,
-                              d_send, d_csize, stream));
-    HFZ_HIP(mark(2, st));
+                              d_send, d_csize, stream, g_timing.enc_span(1)));
   } else {
-    HFZ_HIP(mark(2, st));
     HFZ_HIP(launch_stream_sizes(K, raw, total, frame_bytes, nf, nullptr, const_cast<FrameCode*>(code),
-                                true, d_send, d_csize, stream));
+                                true, d_send, d_csize, stream, g_timing.enc_span(2)));
   }
-  HFZ_HIP(mark(3, st));
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
-                               d_status, stream));
-  HFZ_HIP(mark(4, st));
+                               d_status, stream, g_timing.enc_span(3)));
   HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, code, true, d_send, d_comp_off,
-                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream));
-  HFZ_HIP(mark(5, st));
+                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream, g_timing.enc_span(4)));
   g_timing.cur = nullptr;
   return HFZ_OK;
 }
@@ -534,10 +538,11 @@ int hfz_timing_read(hfz_batch_timing* out) {
                    &out->encode_ms};
   for (size_t c = 0; c < g_timing.enc_calls; ++c) {
     hipEvent_t* ev = &g_timing.enc[c * kEncEvents];
-    HFZ_HIP(hipEventSynchronize(ev[kEncEvents - 1]));
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < kEncSpans; ++i) {
+      if (!((g_timing.enc_used[c] >> i) & 1)) continue;  // that kernel was not part of the call
+      HFZ_HIP(hipEventSynchronize(ev[2 * i + 1]));
       float ms = 0;
-      HFZ_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      HFZ_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
       *dst[i] += ms;
     }
   }

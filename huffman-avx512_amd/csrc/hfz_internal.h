@@ -1,6 +1,7 @@
 // Shared between the host side (hfz_host.cpp) and the kernels (hfz_kernels.hip).
 #pragma once
 
+#include <hip/hip_runtime_api.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -81,15 +82,26 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
 // Records the text of a failed HIP call for hfz_last_hip_error and maps it to an HFZ_E_* code.
 int hip_failure(int hip_error);
 
-// Kernel launchers (hfz_kernels.hip).  All return a hipError_t as int.
+// A pair of events that receive the begin and the end timestamp of ONE kernel's
+// execution (either may be null).  Recording an event on the stream before and
+// after a launch would time the stream's arrival at the markers instead, which
+// adds the dispatch latency (about 5 us) to every kernel.
+struct KernelSpan {
+  hipEvent_t begin = nullptr, end = nullptr;
+};
+
+// Kernel launchers (hfz_kernels.hip).  All return a hipError_t as int.  `span`,
+// where a launcher has one, times the launcher's kernel (nullptr: untimed).
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate = false);
+                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate = false,
+                     const KernelSpan* span = nullptr);
 int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_code, void* stream);
 // d_hist != nullptr: also builds d_code[f] from d_hist[f] (separate-pass encoder);
 // d_hist == nullptr: d_code is given, per frame or (shared_code) one for all frames.
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
-                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
+                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream,
+                        const KernelSpan* span = nullptr);
 // One pass over the input that yields code (build) and stream sizes; usable when
 // count_kernel_fits(): with more than 32 streams its per-stream counters are 16 bits wide.
 inline bool count_kernel_fits(int K, uint64_t frame_bytes) {
@@ -100,23 +112,27 @@ inline bool count_kernel_fits(int K, uint64_t frame_bytes) {
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                  uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
-                 uint32_t* d_csize, void* stream);
+                 uint32_t* d_csize, void* stream, const KernelSpan* span = nullptr);
 // d_given == nullptr: builds d_code[f] from d_hist[f]; otherwise no code is built and the
 // sizes are those under d_given (per frame, or one for all with shared_code).
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
                       FrameCode* d_code, const FrameCode* d_given, bool shared_code,
-                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream);
-int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream);
+                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream,
+                      const KernelSpan* span = nullptr);
+int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream,
+                      const KernelSpan* span = nullptr);
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
-                         int32_t* d_status, void* stream);
+                         int32_t* d_status, void* stream, const KernelSpan* span = nullptr);
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
-                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream);
+                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream,
+                  const KernelSpan* span = nullptr);
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
-                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream);
+                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream,
+                  const KernelSpan* span = nullptr);
 int launch_generate(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index, uint8_t* d_out,
                     uint64_t n, void* stream);
 

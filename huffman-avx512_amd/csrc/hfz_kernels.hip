@@ -4,6 +4,7 @@
 // In the encoder and the decoder one wavefront (64 lanes) owns one frame and one
 // lane one stream of it (two frames per wave for K <= 32 on large batches).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "hfz_internal.h"
 
@@ -1997,6 +1998,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           }
         }
       }
+      STAMP(5);  // lookups
       if (kStore == 2) {
         // A round adds at most 32 bytes, so at most one more block is complete.
         // A lane that completed one tells its neighbour where it goes; the two
@@ -2031,8 +2033,9 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
           if (g_odd) *(uint4*)(obase + (g_odd & ~1u) + 16 * half16) = v_odd;
         }
       }
+      STAMP(6);  // pair stores
     }
-    STAMP(4);  // rounds
+    STAMP(4);  // leaving the rounds
   }
   if (kStore != 2 && sb_full) HFZ_STORE_BLOCK();
   if (kPair64 && sc_full) HFZ_STORE_ODD_BLOCK();
@@ -2126,9 +2129,21 @@ std::atomic<int> g_decoder_store{0};
 // ---------------------------------------------------------------------------
 // launchers
 
+// A launch whose kernel is timed hands the span's events to the runtime with the
+// dispatch (they receive the kernel's own begin and end timestamps).
+#define HFZ_LAUNCH(span, kernel, grid, block, lds, stream, ...)                                    \
+  do {                                                                                             \
+    const KernelSpan* sp_ = (span);                                                                \
+    if (sp_ && (sp_->begin || sp_->end))                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, sp_->begin, sp_->end, 0, __VA_ARGS__); \
+    else                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                           \
+  } while (0)
+
 // accumulate: the counts are added to what d_hist holds (the caller cleared it).
 int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
-                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate) {
+                     uint64_t n_frames, uint32_t* d_hist, void* stream, bool accumulate,
+                     const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (frame_bytes > 0xffffffffull) return hipErrorInvalidValue;  // frame_len() is 32 bits wide
   uint64_t bpf = (frame_bytes + (1u << 16) - 1) >> 16;  // ~64 KiB of input per block
@@ -2139,7 +2154,7 @@ int launch_histogram(const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
     hipError_t e = hipMemsetAsync(d_hist, 0, n_frames * 256 * sizeof(uint32_t), as_stream(stream));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(hist_kernel, dim3((uint32_t)(n_frames * bpf)), dim3(256), 0,
+  HFZ_LAUNCH(span, hist_kernel, dim3((uint32_t)(n_frames * bpf)), dim3(256), 0,
                      as_stream(stream), d_raw, total, frame_bytes, (uint32_t)bpf,
                      accumulate ? 1u : 0u, d_hist);
   return hipGetLastError();
@@ -2157,11 +2172,12 @@ int launch_build_codes(const uint32_t* d_hist, uint64_t n_frames, FrameCode* d_c
 // one record per frame or (shared_code) one for all.
 int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                         uint64_t n_frames, const uint32_t* d_hist, FrameCode* d_code,
-                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+                        bool shared_code, uint32_t* d_stream_end, uint32_t* d_csize, void* stream,
+                        const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   if (d_hist && shared_code) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+  HFZ_LAUNCH(span, sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
                      (uint32_t)K, d_raw, total, frame_bytes, d_hist, d_code,
                      (uint32_t)(d_hist != nullptr), shared_code ? 0u : 1u, d_stream_end, d_csize);
   return hipGetLastError();
@@ -2170,12 +2186,12 @@ int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t fr
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                  uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
-                 uint32_t* d_csize, void* stream) {
+                 uint32_t* d_csize, void* stream, const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   if (!count_kernel_fits(K, frame_bytes)) return hipErrorInvalidValue;
   if (d_counts_out ? d_hist_out == nullptr : d_code == nullptr) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(count_kernel, dim3((uint32_t)n_frames), dim3(kCntThreads), 0,
+  HFZ_LAUNCH(span, count_kernel, dim3((uint32_t)n_frames), dim3(kCntThreads), 0,
                      as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, d_code,
                      shared_code ? 0u : 1u, d_counts_out, d_hist_out, d_stream_end, d_csize);
   return hipGetLastError();
@@ -2183,29 +2199,31 @@ int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_byt
 
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
                       FrameCode* d_code, const FrameCode* d_given, bool shared_code,
-                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream) {
+                      uint32_t* d_stream_end, uint32_t* d_csize, void* stream,
+                      const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+  HFZ_LAUNCH(span, code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
                      (uint32_t)K, d_hist, d_counts, d_code, d_given, shared_code ? 0u : 1u,
                      d_stream_end, d_csize);
   return hipGetLastError();
 }
 
-int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream) {
+int launch_hist_total(const uint32_t* d_hist, uint64_t n_frames, uint64_t* d_total, void* stream,
+                      const KernelSpan* span) {
   hipError_t e = hipMemsetAsync(d_total, 0, 256 * sizeof(uint64_t), as_stream(stream));
   if (e != hipSuccess || n_frames == 0) return e;
   const uint32_t blocks = n_frames < 1024 ? (uint32_t)n_frames : 1024u;
-  hipLaunchKernelGGL(hist_total_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_hist,
+  HFZ_LAUNCH(span, hist_total_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_hist,
                      n_frames, (unsigned long long*)d_total);
   return hipGetLastError();
 }
 
 int launch_frame_offsets(const uint32_t* d_csize, uint64_t n_frames, uint64_t comp_stride,
                          uint64_t comp_cap, uint64_t* d_comp_off, uint32_t* d_comp_size,
-                         int32_t* d_status, void* stream) {
+                         int32_t* d_status, void* stream, const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
-  hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_csize, n_frames,
+  HFZ_LAUNCH(span, offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_csize, n_frames,
                      comp_stride, comp_cap, d_comp_off, d_comp_size, d_status);
   return hipGetLastError();
 }
@@ -2249,7 +2267,8 @@ uint32_t encoder_log2_parts(int K, uint64_t n_frames, uint64_t frame_bytes) {
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
-                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream) {
+                  const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream,
+                  const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   const bool pair = pair_frames(K, n_frames);
@@ -2270,7 +2289,7 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
                                           (int)ring_bytes);                                      \
       if (e_ != hipSuccess) return e_;                                                           \
     }                                                                                            \
-    hipLaunchKernelGGL((encode_kernel<F, B, P>), grid, dim3(threads), ring_bytes,                \
+    HFZ_LAUNCH(span, (encode_kernel<F, B, P>), grid, dim3(threads), ring_bytes,                  \
                        as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames,      \
                        d_code, shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size,     \
                        d_comp, comp_cap, log2_parts);                                            \
@@ -2295,7 +2314,8 @@ constexpr uint64_t kSharedMaxFrame = 128u << 10;
 
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
-                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream) {
+                  uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream,
+                  const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
   if (shared_code && frame_bytes <= kSharedMaxFrame) {
@@ -2305,7 +2325,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     // frames go through the per-frame kernels below, which are faster there
     // (one-wave workgroups pack the CUs better) and decode any frame.
     const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
-    hipLaunchKernelGGL((decode_kernel<12, kSharedWaves, 1, 0>), dim3((uint32_t)groups),
+    HFZ_LAUNCH(span, (decode_kernel<12, kSharedWaves, 1, 0>), dim3((uint32_t)groups),
                        dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
                        comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
                        d_status);
@@ -2318,31 +2338,31 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
   if (tab_bits == HFZ_DECODER_TABLE_FREE) {
     // only on request (tests, comparison): one symbol per step, no lookup table
-    hipLaunchKernelGGL((decode_kernel<0, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
+    HFZ_LAUNCH(span, (decode_kernel<0, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
     return hipGetLastError();
   }
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
-    hipLaunchKernelGGL((decode_kernel<11, 1, 2, 0>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
+    HFZ_LAUNCH(span, (decode_kernel<11, 1, 2, 0>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
     return hipGetLastError();
   }
   const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
-    hipLaunchKernelGGL((decode_kernel<12, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
+    HFZ_LAUNCH(span, (decode_kernel<12, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   else if (g_decoder_store.load(std::memory_order_relaxed)
                ? g_decoder_store.load(std::memory_order_relaxed) == 2
                : frame_bytes <= kPairStoreMaxSlice * (uint64_t)K)
-    hipLaunchKernelGGL((decode_kernel<11, 1, 1, 2>), dim3((uint32_t)n_frames), dim3(64), 0,
+    HFZ_LAUNCH(span, (decode_kernel<11, 1, 1, 2>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   else
-    hipLaunchKernelGGL((decode_kernel<11, 1, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
+    HFZ_LAUNCH(span, (decode_kernel<11, 1, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
                        as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
                        n_frames, d_raw, raw_cap, frame_bytes, d_status);
   return hipGetLastError();

@@ -243,14 +243,16 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
                             uint32_t* d_hist, void* stream);
 
 /*
- * Optional per-kernel timing of the batch entry points, taken with HIP events
- * on the caller's stream (used by the benchmark to price each kernel against
- * its roofline).  hfz_timing_enable(n), n >= 1, makes every n-th of the following
- * batch calls of each kind on this thread (the first included) record an event
- * before and after each of its kernels (at most 512 recorded calls of each kind
- * between reads); 0 turns it off.  Events between kernels stop one kernel's
- * tail from overlapping the next kernel's start, about 5 % of a 256 MiB batch,
- * so a benchmark samples (n = 4) rather than timing every call.
+ * Optional per-kernel timing of the batch entry points (used by the benchmark
+ * to price each kernel against its roofline).  hfz_timing_enable(n), n >= 1,
+ * makes every n-th of the following batch calls of each kind on this thread
+ * (the first included) launch each of its kernels with a pair of HIP events that
+ * receive the kernel's own begin and end timestamps (hipExtLaunchKernelGGL), so
+ * a kernel's time is its execution alone, without the dispatch latency that an
+ * event recorded on the stream before the launch would add (at most 512
+ * recorded calls of each kind between reads); 0 turns it off.  A timed launch
+ * stops one kernel's tail from overlapping the next kernel's start, about 5 %
+ * of a 256 MiB batch, so a benchmark samples (n = 4) rather than timing every call.
  * hfz_timing_read waits for the events, returns the mean milliseconds per call
  * of each kernel over the calls recorded since the previous read, and starts a
  * new window.  hfz_timing_enable(0) also destroys the events.  Has no

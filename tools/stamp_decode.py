@@ -14,7 +14,7 @@ hfz = importlib.import_module("huffman-avx512_amd")
 hfz.LIB_PATH = os.path.join(ROOT, "tools", "libhfz_stamp.so")
 L = hfz.lib()
 geometric_cdf = hfz.distributions.geometric_cdf
-names = ["header", "table", "priming", "staging", "rounds", "-", "-", "tail"]
+names = ["header", "table", "priming", "staging", "rounds: loop", "rounds: lookups", "rounds: pair stores", "tail"]
 SRC = os.environ.get("HFZ_SRC", "biased")
 K = int(os.environ.get("HFZ_K", "64"))
 for frame_kib in [int(a) for a in sys.argv[1:]] or [64]:
