@@ -717,6 +717,54 @@ def test_command_line_tool_round_trip(torch_cuda, tmp_path):
 
 # ---- randomized sweep ----------------------------------------------------------
 
+def test_kernel_timing_reports_every_kernel_of_a_timed_call(torch_cuda):
+    """hfz_timing_*: every n-th call is timed, each kernel that ran has a positive
+    time and the ones that did not read zero; switching it off leaves the codec
+    results untouched (the timed launches go through another launch call)."""
+    torch = torch_cuda
+    raw = hfz.generate(hfz.distributions.geometric_cdf(), 77, 4 << 20)
+    try:
+        # counting path: count + code/sizes + placement + encode, no separate sizes pass
+        codec = hfz.BatchCodec(64, 4 << 20, 128 << 10)
+        hfz.timing_enable(2)
+        for _ in range(4):
+            batch = codec.compress(raw)
+            out = codec.decompress(batch)
+        torch.cuda.synchronize()
+        t = hfz.timing_read()
+        assert t["compress_calls"] == 2 and t["decompress_calls"] == 2 and t["count_calls"] == 0
+        for name in ("hist_ms", "table_ms", "place_ms", "encode_ms", "decode_ms"):
+            assert 0 < t[name] < 50, (name, t)
+        assert t["sizes_ms"] == 0 and t["count_ms"] == 0
+        assert torch.equal(out, raw)
+        # a read starts a new window
+        t = hfz.timing_read()
+        assert t["compress_calls"] == 0 and t["decode_ms"] == 0
+        # slices beyond 64 KiB: histogram + sizes pass instead of the counting kernel
+        big = hfz.BatchCodec(64, 4 << 20, 4 << 20)
+        hfz.timing_enable(1)
+        batch = big.compress(raw)
+        out = big.decompress(batch)
+        torch.cuda.synchronize()
+        t = hfz.timing_read()
+        assert t["compress_calls"] == 1 and t["decompress_calls"] == 1
+        assert t["hist_ms"] > 0 and t["sizes_ms"] > 0 and t["table_ms"] == 0 and t["encode_ms"] > 0
+        assert torch.equal(out, raw)
+        # the two-step shared-code encoder: the input pass is timed on its own
+        hist = codec.count(raw)
+        code = codec.code_from_histogram(hist.cpu().numpy())
+        batch = codec.compress(raw, code=code, counted=True)
+        out = codec.decompress(batch, shared=True)
+        torch.cuda.synchronize()
+        t = hfz.timing_read()
+        assert t["count_calls"] == 1 and t["count_ms"] > 0 and t["hist_ms"] == 0
+        assert t["table_ms"] > 0 and t["encode_ms"] > 0 and t["decode_ms"] > 0
+        assert torch.equal(out, raw)
+    finally:
+        hfz.timing_enable(0)
+    assert hfz.timing_read()["compress_calls"] == 0
+
+
 def test_random_batches_equal_oracle(torch_cuda):
     # fixed-seed sweep over stream counts, frame sizes (down to a few bytes), batch
     # shapes, layouts and sources, under both decoder tables and both lane mappings
