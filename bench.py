@@ -130,6 +130,12 @@ def main():
     ap.add_argument("--time-every", type=int, default=4,
                     help="HIP events around each kernel on every n-th step of the timed region "
                          "(events between kernels cost about 5 %% of a step, so they are sampled)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="independent batches in flight, each on a HIP stream of its own, steps "
+                         "taking them in turn (1 = every step behind the one before it, which is "
+                         "what the per-kernel times and the roofline are quoted on; with 2 the "
+                         "serial code construction of one batch runs beside the memory-bound "
+                         "passes of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
@@ -163,29 +169,48 @@ def main():
     total = args.total_mib << 20
     frame_bytes = args.frame_kib << 10
     cdf = hfz.distributions.SOURCES[args.source]()
-    raw = hfz.generate(cdf, 1000 + rank, total, device=dev)
-    codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
-    out = torch.empty(total, dtype=torch.uint8, device=dev)
-    code = torch.zeros(792, dtype=torch.uint8, device=dev)
+    n_slots = max(1, args.in_flight)
 
-    def shared_code():
+    class Slot:
+        """One batch with everything a step on it touches."""
+        def __init__(self, i):
+            self.raw = hfz.generate(cdf, 1000 + rank + 7919 * i, total, device=dev)
+            self.codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
+            self.out = torch.empty(total, dtype=torch.uint8, device=dev)
+            self.code = torch.zeros(792, dtype=torch.uint8, device=dev)
+            self.stream = torch.cuda.Stream(dev) if n_slots > 1 else None
+
+    slots = [Slot(i) for i in range(n_slots)]
+    torch.cuda.synchronize(dev)
+    raw, codec, out = slots[0].raw, slots[0].codec, slots[0].out
+    turn = [0]
+
+    def shared_code(sl):
         # one pass over the batch leaves per-stream counts in the workspace and the
         # 256 byte counts in a device tensor; those are summed over ranks (the job's
         # one exchange) and the code is built on the device from the sum
-        h32 = job_histogram(hfz, codec.count(raw), world)
-        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, code.data_ptr(),
+        h32 = job_histogram(hfz, sl.codec.count(sl.raw), world)
+        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, sl.code.data_ptr(),
                                    torch.cuda.current_stream(dev).cuda_stream)
         assert rc == 0, rc
-        return code
+        return sl.code
+
+    def step_on(sl):
+        if args.shared_table:
+            batch = sl.codec.compress(sl.raw, code=shared_code(sl), counted=True)
+            sl.codec.decompress(batch, sl.out, shared=True)
+        else:
+            batch = sl.codec.compress(sl.raw)
+            sl.codec.decompress(batch, sl.out)
+        return batch
 
     def step():
-        if args.shared_table:
-            batch = codec.compress(raw, code=shared_code(), counted=True)
-            codec.decompress(batch, out, shared=True)
-        else:
-            batch = codec.compress(raw)
-            codec.decompress(batch, out)
-        return batch
+        sl = slots[turn[0] % n_slots]
+        turn[0] += 1
+        if sl.stream is None:
+            return step_on(sl)
+        with torch.cuda.stream(sl.stream):
+            return step_on(sl)
 
     for _ in range(args.warmup):
         step()
@@ -196,8 +221,10 @@ def main():
     hfz.timing_enable(False)
 
     # correctness of what was timed
-    assert torch.equal(out, raw), "round trip mismatch"
-    assert int(codec.status.abs().sum().item()) == 0 and int(codec.dstatus.abs().sum().item()) == 0
+    for sl in slots:
+        assert torch.equal(sl.out, sl.raw), "round trip mismatch"
+        assert int(sl.codec.status.abs().sum().item()) == 0
+        assert int(sl.codec.dstatus.abs().sum().item()) == 0
     comp_bytes = batch.compressed_bytes()
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -249,7 +276,7 @@ def main():
                    "source": args.source,
                    "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
                    "frames_per_gpu": codec.n_frames, "compressed_over_raw": round(C / N, 4),
-                   "layout": "packed"},
+                   "layout": "packed", "batches_in_flight": n_slots},
         # sums of kernel times, the input pass of the shared-table mode included
         "encode_MiBps_kernels": round(mib / (enc_ms * 1e-3), 1) if enc_ms > 0 else None,
         "decode_MiBps_kernels": round(mib / (kt["decode_ms"] * 1e-3), 1) if kt["decode_ms"] > 0 else None,
