@@ -28,6 +28,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 METRIC = "MiB/s encode+decode on 256-sym biased input; achieved HBM GB/s vs peak"
 
+# --force-dist: a one-rank job takes every branch a multi-rank job takes (process
+# group, barriers, all-reduces), so those branches can be run on a single GPU.
+FORCE_DIST = False
+
+
+def _dist_on(world):
+    return world > 1 or FORCE_DIST
+
 
 # ---- job bookkeeping (runs under gloo on CPU as well) -------------------------
 
@@ -36,7 +44,7 @@ def job_barrier(world, cuda):
     import torch
     if cuda:
         torch.cuda.synchronize()
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         dist.barrier()
     if cuda:
@@ -45,7 +53,7 @@ def job_barrier(world, cuda):
 
 def max_over_ranks(seconds, world, device):
     """The slowest rank's time: what the whole job took."""
-    if world <= 1:
+    if not _dist_on(world):
         return float(seconds)
     import torch
     import torch.distributed as dist
@@ -60,7 +68,7 @@ def job_histogram(hfz, h, world):
     builders take.  Returns the int32 tensor of uint32 bit patterns, identical on
     every rank."""
     h = h.clone()
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         dist.all_reduce(h)
     return hfz.scale_histogram_dev(h)
@@ -109,7 +117,129 @@ def kernel_table(kt, alg_bytes, shared_table):
     return out, ms_of, ran
 
 
+class Workload:
+    """One benchmark workload on one device: buffers, the step, its measurement."""
+
+    def __init__(self, hfz, dev, rank, world, K, total_mib, frame_kib, source, shared_table,
+                 in_flight=1):
+        import torch
+        self.torch, self.hfz, self.L, self.dev, self.rank, self.world = torch, hfz, hfz.lib(), dev, rank, world
+        self.K, self.total_mib, self.frame_kib = K, total_mib, frame_kib
+        self.source, self.shared_table = source, bool(shared_table)
+        self.total = total_mib << 20
+        self.frame_bytes = frame_kib << 10
+        self.cdf = hfz.distributions.SOURCES[source]()
+        self.slots = [self._slot(i, in_flight > 1) for i in range(max(1, in_flight))]
+        torch.cuda.synchronize(dev)
+        self.turn = 0
+
+    def _slot(self, i, own_stream):
+        torch, hfz, dev = self.torch, self.hfz, self.dev
+
+        class Slot:
+            """One batch with everything a step on it touches."""
+        sl = Slot()
+        sl.raw = hfz.generate(self.cdf, 1000 + self.rank + 7919 * i, self.total, device=dev)
+        sl.codec = hfz.BatchCodec(self.K, self.total, self.frame_bytes, device=dev)
+        sl.out = torch.empty(self.total, dtype=torch.uint8, device=dev)
+        sl.code = torch.zeros(792, dtype=torch.uint8, device=dev)
+        sl.stream = torch.cuda.Stream(dev) if own_stream else None
+        return sl
+
+    def add_slot(self):
+        """A second batch, and a stream for each: the two-batches-in-flight figure."""
+        torch = self.torch
+        second = self._slot(len(self.slots), True)
+        for sl in self.slots:
+            if sl.stream is None:
+                sl.stream = torch.cuda.Stream(self.dev)
+        self.slots.append(second)
+        torch.cuda.synchronize(self.dev)
+
+    def _shared_code(self, sl):
+        # one pass over the batch leaves per-stream counts in the workspace and the
+        # 256 byte counts in a device tensor; those are summed over ranks (the job's
+        # one exchange) and the code is built on the device from the sum
+        h32 = job_histogram(self.hfz, sl.codec.count(sl.raw), self.world)
+        rc = self.L.hfz_build_codes_dev(h32.data_ptr(), 1, sl.code.data_ptr(),
+                                        self.torch.cuda.current_stream(self.dev).cuda_stream)
+        assert rc == 0, rc
+        return sl.code
+
+    def _step_on(self, sl):
+        if self.shared_table:
+            batch = sl.codec.compress(sl.raw, code=self._shared_code(sl), counted=True)
+            sl.codec.decompress(batch, sl.out, shared=True)
+        else:
+            batch = sl.codec.compress(sl.raw)
+            sl.codec.decompress(batch, sl.out)
+        return batch
+
+    def step(self):
+        sl = self.slots[self.turn % len(self.slots)]
+        self.turn += 1
+        if sl.stream is None:
+            return self._step_on(sl)
+        with self.torch.cuda.stream(sl.stream):
+            return self._step_on(sl)
+
+    def check(self, what=""):
+        """Correctness of what was timed."""
+        torch = self.torch
+        for sl in self.slots:
+            assert torch.equal(sl.out, sl.raw), "round trip mismatch" + what
+            assert int(sl.codec.status.abs().sum().item()) == 0
+            assert int(sl.codec.dstatus.abs().sum().item()) == 0
+
+    def timed(self, steps, warmup, time_every):
+        """(seconds of the slowest rank, last batch, per-kernel timing dict)."""
+        hfz = self.hfz
+        for _ in range(warmup):
+            self.step()
+        job_barrier(self.world, True)
+        hfz.timing_enable(max(1, min(time_every, steps)) if time_every else 0)
+        elapsed, batch = time_steps(self.step, steps, 0, self.world, True, self.dev)
+        kt = hfz.timing_read()
+        hfz.timing_enable(False)
+        self.check()
+        return elapsed, batch, kt
+
+    def describe(self):
+        return "%d-stream encode+decode, %d MiB %s synthetic per GPU, %d KiB frames, %s" % (
+            self.K, self.total_mib,
+            "biased-geometric" if self.source == "biased" else "enwik8-like", self.frame_kib,
+            "one shared code (device histogram summed over ranks), tables in LDS"
+            if self.shared_table else "per-frame tables in LDS")
+
+
+def side_measurement(hfz, dev, rank, K, total_mib, frame_kib, source, steps, warmup, time_every):
+    """A further workload measured after the headline one (one rank): whole-step
+    throughput and the decoder's algorithmic rate against the HBM peak."""
+    import torch
+    w = Workload(hfz, dev, rank, 1, K, total_mib, frame_kib, source, False)
+    elapsed, batch, kt = w.timed(steps, warmup, time_every)
+    N, C = float(w.total), float(batch.compressed_bytes())
+    mib = w.total / float(1 << 20)
+    ent = {"workload": w.describe(), "value": round(job_value(1, mib, elapsed, steps), 1),
+           "unit": "MiB/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 4),
+           "frames": w.slots[0].codec.n_frames, "compressed_over_raw": round(C / N, 4)}
+    enc_ms = kt["hist_ms"] + kt["table_ms"] + kt["sizes_ms"] + kt["place_ms"] + kt["encode_ms"]
+    if kt["decode_ms"] > 0:
+        gbps = (C + N) / (kt["decode_ms"] * 1e-3) / 1e9
+        ent["decode"] = {"ms": round(kt["decode_ms"], 4), "GBps": round(gbps, 1),
+                         "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+    if kt["encode_ms"] > 0:
+        gbps = (C + N) / (kt["encode_ms"] * 1e-3) / 1e9
+        ent["encode"] = {"ms": round(kt["encode_ms"], 4), "GBps": round(gbps, 1),
+                         "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "all_encoder_kernels_ms": round(enc_ms, 4)}
+    del w
+    torch.cuda.empty_cache()
+    return ent
+
+
 def main():
+    global FORCE_DIST
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -138,7 +268,13 @@ def main():
                          "passes of the other)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra measurement with two batches in flight")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the extra workloads measured after the headline one "
+                         "(32-stream text-like 1 GiB; the headline batch in 1 MiB frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank branches (process group over RCCL, barriers, "
+                         "all-reduces) even with one rank, so that they can be run on one GPU")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 PMC passes, if collected")
     presets = {2: {}, 3: dict(streams=32, total_mib=1024, source="enwik", frame_kib=512),
@@ -148,6 +284,7 @@ def main():
     if pre.config:
         ap.set_defaults(**presets[pre.config])
     args = ap.parse_args()
+    FORCE_DIST = bool(args.force_dist)
 
     import torch
     import torch.distributed as dist
@@ -160,73 +297,22 @@ def main():
                          (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if _dist_on(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     hfz = importlib.import_module("huffman-avx512_amd")
-    L = hfz.lib()  # fails loudly if the HIP library is missing
+    hfz.lib()  # fails loudly if the HIP library is missing
 
     K = args.streams
     total = args.total_mib << 20
     frame_bytes = args.frame_kib << 10
-    cdf = hfz.distributions.SOURCES[args.source]()
-    n_slots = max(1, args.in_flight)
-
-    class Slot:
-        """One batch with everything a step on it touches."""
-        def __init__(self, i):
-            self.raw = hfz.generate(cdf, 1000 + rank + 7919 * i, total, device=dev)
-            self.codec = hfz.BatchCodec(K, total, frame_bytes, device=dev)
-            self.out = torch.empty(total, dtype=torch.uint8, device=dev)
-            self.code = torch.zeros(792, dtype=torch.uint8, device=dev)
-            self.stream = torch.cuda.Stream(dev) if n_slots > 1 else None
-
-    slots = [Slot(i) for i in range(n_slots)]
-    torch.cuda.synchronize(dev)
-    raw, codec, out = slots[0].raw, slots[0].codec, slots[0].out
-    turn = [0]
-
-    def shared_code(sl):
-        # one pass over the batch leaves per-stream counts in the workspace and the
-        # 256 byte counts in a device tensor; those are summed over ranks (the job's
-        # one exchange) and the code is built on the device from the sum
-        h32 = job_histogram(hfz, sl.codec.count(sl.raw), world)
-        rc = L.hfz_build_codes_dev(h32.data_ptr(), 1, sl.code.data_ptr(),
-                                   torch.cuda.current_stream(dev).cuda_stream)
-        assert rc == 0, rc
-        return sl.code
-
-    def step_on(sl):
-        if args.shared_table:
-            batch = sl.codec.compress(sl.raw, code=shared_code(sl), counted=True)
-            sl.codec.decompress(batch, sl.out, shared=True)
-        else:
-            batch = sl.codec.compress(sl.raw)
-            sl.codec.decompress(batch, sl.out)
-        return batch
-
-    def step():
-        sl = slots[turn[0] % n_slots]
-        turn[0] += 1
-        if sl.stream is None:
-            return step_on(sl)
-        with torch.cuda.stream(sl.stream):
-            return step_on(sl)
-
-    for _ in range(args.warmup):
-        step()
-    job_barrier(world, True)
-    hfz.timing_enable(max(1, min(args.time_every, args.steps)))
-    elapsed, batch = time_steps(step, args.steps, 0, world, True, dev)
-    kt = hfz.timing_read()
-    hfz.timing_enable(False)
-
-    # correctness of what was timed
-    for sl in slots:
-        assert torch.equal(sl.out, sl.raw), "round trip mismatch"
-        assert int(sl.codec.status.abs().sum().item()) == 0
-        assert int(sl.codec.dstatus.abs().sum().item()) == 0
+    work = Workload(hfz, dev, rank, world, K, args.total_mib, args.frame_kib, args.source,
+                    args.shared_table, args.in_flight)
+    n_slots = len(work.slots)
+    raw, codec = work.slots[0].raw, work.slots[0].codec
+    elapsed, batch, kt = work.timed(args.steps, args.warmup, args.time_every)
     comp_bytes = batch.compressed_bytes()
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -267,13 +353,7 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "%d-stream encode+decode, %d MiB %s synthetic per GPU, "
-                               "%d KiB frames, %s" % (
-                                   K, args.total_mib,
-                                   "biased-geometric" if args.source == "biased" else "enwik8-like",
-                                   args.frame_kib,
-                                   "one shared code (device histogram summed over ranks), tables "
-                                   "in LDS" if args.shared_table else "per-frame tables in LDS"),
+        "config": {"workload": work.describe(),
                    "shared_table": bool(args.shared_table),
                    "source": args.source,
                    "streams": K, "raw_mib_per_gpu": args.total_mib, "frame_kib": args.frame_kib,
@@ -285,21 +365,17 @@ def main():
         "kernels": kernels,
         "roofline": roofline,
     }
+    if FORCE_DIST:
+        result["forced_dist"] = True
 
     # The same steps with two batches in flight (a caller with a queue of batches):
     # an extra figure beside `value`, measured after it, on one GPU and for batches
     # small enough that a second set of buffers is no burden.
     if world == 1 and n_slots == 1 and not args.no_pipelined and args.total_mib <= 2048:
         try:
-            hfz.timing_enable(False)
-            second = Slot(1)
-            second.stream, slots[0].stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-            slots.append(second)
-            n_slots = 2
-            torch.cuda.synchronize(dev)
-            p_elapsed, _ = time_steps(step, args.steps, 2, world, True, dev)
-            for sl in slots:
-                assert torch.equal(sl.out, sl.raw), "round trip mismatch (two batches in flight)"
+            work.add_slot()
+            p_elapsed, _ = time_steps(work.step, args.steps, 2, world, True, dev)
+            work.check(" (two batches in flight)")
             result["pipelined"] = {"batches_in_flight": 2,
                                    "value": round(job_value(world, mib, p_elapsed, args.steps), 1),
                                    "unit": "MiB/s", "ms_per_step": round(1e3 * p_elapsed / args.steps, 4),
@@ -309,11 +385,30 @@ def main():
         except RuntimeError as e:  # e.g. no room for the second set of buffers: `value` stands
             result["pipelined"] = {"error": str(e)[:200]}
 
+    # Two more workloads beside the headline one, each a short run of its own after
+    # it (one rank, default workload only): the 32-stream format on 1 GiB of
+    # text-like data (BASELINE config[2]) and the headline batch cut into 1 MiB
+    # frames (the frame size config[3] names), where a batch has 256 frames.
+    default_line = (K == 64 and args.total_mib == 256 and args.frame_kib == 128 and
+                    args.source == "biased" and not args.shared_table and args.in_flight == 1)
+    if world == 1 and default_line and not args.no_side:
+        host_raw = raw[:min(total, 32 << 20)].cpu() if not args.no_cpu_baseline else None
+        del work, raw, codec, batch
+        torch.cuda.empty_cache()
+        for name, kw in (("k32_enwik", dict(K=32, total_mib=1024, frame_kib=512, source="enwik")),
+                         ("frames_1mib", dict(K=64, total_mib=256, frame_kib=1024, source="biased"))):
+            try:
+                result[name] = side_measurement(hfz, dev, rank, steps=10, warmup=2,
+                                                time_every=args.time_every, **kw)
+            except RuntimeError as e:
+                result[name] = {"error": str(e)[:200]}
+        raw = host_raw
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(raw, total, K, frame_bytes, args.frame_kib)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if _dist_on(world):
         dist.destroy_process_group()
 
 
@@ -324,11 +419,17 @@ def cpu_baseline(raw, total, K, frame_bytes, frame_kib):
     import oracle
     sample = min(total, 32 << 20)
     host = raw[:sample].cpu().numpy()
+    # threads used: the box's share for one GPU (OMP_NUM_THREADS there), not the
+    # machine's core count, which host_cores reports beside it
     try:
         cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     except ValueError:
         cores = min(16, os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
 
     def leg(K_, data, fb, threads, seconds):
         tc, td, _ = oracle.time_roundtrip(K_, data, fb, 1, threads)
@@ -345,6 +446,7 @@ def cpu_baseline(raw, total, K, frame_bytes, frame_kib):
     k32 = leg(32, host, frame_bytes, 1, 3.0)  # the reference's widest scalar instantiation
     return {
         "value": multi["value"], "unit": "MiB/s", "cores": cores, "kind": "port",
+        "host_cores": os.cpu_count(), "host_cores_usable": usable,
         "encode_MiBps": multi["encode_MiBps"], "decode_MiBps": multi["decode_MiBps"],
         "sample": "first %d MiB of rank 0's batch (%d frames of %d KiB, K=%d), %d repetitions of "
                   "whole-call compress+decompress with the scalar C restatement of the "

@@ -536,6 +536,7 @@ int hfz_timing_read(hfz_batch_timing* out) {
   std::memset(out, 0, sizeof(*out));
   float* dst[5] = {&out->hist_ms, &out->table_ms, &out->sizes_ms, &out->place_ms,
                    &out->encode_ms};
+  size_t launched[5] = {0, 0, 0, 0, 0};  // timed calls that ran kernel i
   for (size_t c = 0; c < g_timing.enc_calls; ++c) {
     hipEvent_t* ev = &g_timing.enc[c * kEncEvents];
     for (int i = 0; i < kEncSpans; ++i) {
@@ -544,6 +545,7 @@ int hfz_timing_read(hfz_batch_timing* out) {
       float ms = 0;
       HFZ_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
       *dst[i] += ms;
+      ++launched[i];
     }
   }
   for (size_t c = 0; c < g_timing.dec_calls; ++c) {
@@ -560,8 +562,10 @@ int hfz_timing_read(hfz_batch_timing* out) {
     HFZ_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out->count_ms += ms;
   }
-  if (g_timing.enc_calls)
-    for (int i = 0; i < 5; ++i) *dst[i] /= (float)g_timing.enc_calls;
+  // a kernel's mean is over the calls that launched it (a window may mix the
+  // counting path, the separate-pass path and the shared-code variants)
+  for (int i = 0; i < 5; ++i)
+    if (launched[i]) *dst[i] /= (float)launched[i];
   if (g_timing.dec_calls) out->decode_ms /= (float)g_timing.dec_calls;
   if (g_timing.cnt_calls) out->count_ms /= (float)g_timing.cnt_calls;
   out->compress_calls = (int32_t)g_timing.enc_calls;
@@ -796,11 +800,16 @@ int hfz_decompress(int K, const void* src, size_t n, void* dst, size_t cap, size
     if (status != HFZ_OK) return status;
     if (raw_size) std::memcpy(dst, ar.pin + 32, raw_size);
   } else {
+    // the frame's status first: dst stays untouched when the frame is refused, as
+    // on the staged path
     HFZ_HIP(hipMemcpyAsync(ar.pin, ar.dev + o_back, 32, hipMemcpyDeviceToHost, st));
-    if (raw_size) HFZ_HIP(hipMemcpyAsync(dst, ar.dev + o_raw, raw_size, hipMemcpyDeviceToHost, st));
     HFZ_HIP(hipStreamSynchronize(st));
     std::memcpy(&status, ar.pin + 16, 4);
     if (status != HFZ_OK) return status;
+    if (raw_size) {
+      HFZ_HIP(hipMemcpyAsync(dst, ar.dev + o_raw, raw_size, hipMemcpyDeviceToHost, st));
+      HFZ_HIP(hipStreamSynchronize(st));
+    }
   }
   return HFZ_OK;
 }

@@ -2244,6 +2244,18 @@ int device_cus() {
   return cus;
 }
 
+// LDS a workgroup may use on the current device (160 KiB on gfx950, the only
+// target of this code object; asked for all the same, so that a launch is sized
+// to what the device says rather than to a constant).
+size_t device_lds_per_block() {
+  int dev = 0, bytes = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+      bytes <= 0)
+    bytes = 64 << 10;
+  return (size_t)bytes;
+}
+
 // Parts per stream (as a power of two) for a batch: none while one wave per
 // frame fills the chip four waves per CU, else as many as it takes to get there,
 // within 512 threads per frame and no less than 512 bytes per part.
@@ -2275,12 +2287,18 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
   const int enc_blk = g_encoder_block.load(std::memory_order_relaxed);
   const bool wide = enc_blk ? enc_blk == 64
                             : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
-  const uint32_t log2_parts = pair ? 0 : encoder_log2_parts(K, n_frames, frame_bytes);
+  uint32_t log2_parts = pair ? 0 : encoder_log2_parts(K, n_frames, frame_bytes);
   const dim3 grid((uint32_t)(pair ? (n_frames + 1) / 2 : n_frames));
-  const uint32_t threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
   // the rings of a parts launch: 8 KiB per wave of dynamic LDS (beyond the 64 KiB a
-  // launch may ask for by default when all eight waves are used)
-  const size_t ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
+  // launch may ask for by default when all eight waves are used), next to 2 KiB of
+  // static LDS; fewer parts where the device gives a workgroup less than that
+  uint32_t threads;
+  size_t ring_bytes;
+  for (;; --log2_parts) {
+    threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
+    ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
+    if (log2_parts == 0 || ring_bytes + 2048 <= device_lds_per_block()) break;
+  }
 #define HFZ_LAUNCH_ENCODE(F, B, P)                                                               \
   do {                                                                                           \
     if (ring_bytes > (48u << 10)) {                                                              \

@@ -253,9 +253,9 @@ int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes,
  * recorded calls of each kind between reads); 0 turns it off.  A timed launch
  * stops one kernel's tail from overlapping the next kernel's start, about 5 %
  * of a 256 MiB batch, so a benchmark samples (n = 4) rather than timing every call.
- * hfz_timing_read waits for the events, returns the mean milliseconds per call
- * of each kernel over the calls recorded since the previous read, and starts a
- * new window.  hfz_timing_enable(0) also destroys the events.  Has no
+ * hfz_timing_read waits for the events, returns for each kernel the mean
+ * milliseconds over the recorded calls that launched it since the previous read
+ * (0 for a kernel none of them launched), and starts a new window.  hfz_timing_enable(0) also destroys the events.  Has no
  * counterpart in the reference.
  */
 typedef struct hfz_batch_timing {

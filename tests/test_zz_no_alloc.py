@@ -95,3 +95,99 @@ def test_static_workspace_encoder_refuses_too_many_frames():
                                          size.data_ptr(), None, None)
     assert rc == 0
     torch.cuda.synchronize()
+
+
+# ---- under HIP graph capture ---------------------------------------------------
+
+def _hip_runtime():
+    """The HIP runtime this process already uses (torch and libhfz.so share it),
+    found in the process map so that no second copy gets loaded."""
+    import ctypes
+    path = None
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            if "libamdhip64.so" in line:
+                path = line.split()[-1]
+                break
+    assert path, "HIP runtime not loaded"
+    hip = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    hip.hipStreamBeginCapture.argtypes = [vp, ctypes.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, ctypes.POINTER(vp)]
+    hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ctypes.c_size_t]
+    hip.hipGraphLaunch.argtypes = [vp, vp]
+    hip.hipGraphExecDestroy.argtypes = [vp]
+    hip.hipGraphDestroy.argtypes = [vp]
+    hip.hipGraphGetNodes.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_size_t)]
+    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    return hip
+
+
+@pytest.mark.parametrize("K,n_frames,frame_bytes", [
+    (64, 200, 64 << 10),   # one wave per frame, counting kernel
+    (64, 3, 256 << 10),    # few frames: several threads per stream, 64 KiB of dynamic LDS
+    (32, 9, 50000),        # 32 streams, ragged sizes
+])
+def test_static_workspace_encoder_records_into_a_hip_graph(K, n_frames, frame_bytes):
+    """What the entry point exists for: a call between hipStreamBeginCapture and
+    hipStreamEndCapture (global mode: any allocation, free or synchronisation by
+    any thread would fail the capture) records the whole batch encoder, and the
+    graph, replayed on fresh inputs, writes the frames hfz_compress_batch_dev writes."""
+    import ctypes
+    import torch
+    L = hfz.lib()
+    hip = _hip_runtime()
+    assert L.hfz_static_workspace_init() == 0
+    total = n_frames * frame_bytes - 321
+    cdf = geometric_cdf()
+    inputs = [hfz.generate(cdf, 100 + i, total) for i in range(3)]
+    ref = hfz.BatchCodec(K, total, frame_bytes)
+    raw = torch.empty(total, dtype=torch.uint8, device="cuda")
+    comp = torch.empty(ref.comp_cap, dtype=torch.uint8, device="cuda")
+    off = torch.zeros(ref.n_frames, dtype=torch.int64, device="cuda")
+    size = torch.zeros(ref.n_frames, dtype=torch.int32, device="cuda")
+    status = torch.zeros(ref.n_frames, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+
+    def call():
+        return L.hfz_compress_batch_static_dev(K, raw.data_ptr(), total, frame_bytes, comp.data_ptr(),
+                                               ref.comp_cap, 0, off.data_ptr(), size.data_ptr(),
+                                               status.data_ptr(), st.cuda_stream)
+
+    # first use outside a capture (the runtime loads the kernels on their first launch)
+    raw.copy_(inputs[0])
+    torch.cuda.synchronize()
+    assert call() == 0
+    torch.cuda.synchronize()
+    free0, tot0 = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(tot0)) == 0
+
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(st.cuda_stream, 0) == 0   # hipStreamCaptureModeGlobal
+    rc = call()
+    end = hip.hipStreamEndCapture(st.cuda_stream, ctypes.byref(graph))
+    assert rc == 0 and end == 0 and graph.value, (rc, end)
+    n_nodes = ctypes.c_size_t()
+    assert hip.hipGraphGetNodes(graph, None, ctypes.byref(n_nodes)) == 0
+    assert n_nodes.value >= 4  # counting, code + sizes, placement, encode (or their separate-pass twins)
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    free1, tot1 = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(tot1)) == 0
+    try:
+        for data in inputs[1:]:
+            raw.copy_(data)
+            comp.fill_(0xEE)
+            torch.cuda.synchronize()
+            assert hip.hipGraphLaunch(gexec, st.cuda_stream) == 0
+            st.synchronize()
+            want = ref.compress(data)
+            torch.cuda.synchronize()
+            assert status.cpu().tolist() == [0] * ref.n_frames
+            assert torch.equal(off, want.comp_off) and torch.equal(size, want.comp_size)
+            end_of_frames = int(off[-1].item()) + int(size[-1].item())
+            assert torch.equal(comp[:end_of_frames], want.comp[:end_of_frames])
+    finally:
+        hip.hipGraphExecDestroy(gexec)
+        hip.hipGraphDestroy(graph)
+    # the captured call took no device memory (instantiating the graph is the caller's business)
+    assert free1.value >= free0.value - (8 << 20), (free0.value, free1.value)
