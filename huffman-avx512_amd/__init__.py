@@ -41,7 +41,7 @@ EXPORTS = (
     "hfz_compress_batch_shared_dev", "hfz_decompress_batch_shared_dev", "hfz_set_frames_per_wave",
     "hfz_count_batch_dev", "hfz_compress_batch_counted_dev", "hfz_set_encoder_block",
     "hfz_static_workspace_init", "hfz_static_max_frames", "hfz_compress_batch_static_dev",
-    "hfz_set_decoder_store", "hfz_set_encoder_parts",
+    "hfz_set_decoder_store", "hfz_set_encoder_parts", "hfz_set_decoder_parts",
 )
 
 
@@ -148,6 +148,8 @@ def lib():
         L.hfz_set_encoder_block.argtypes = [ci]
         L.hfz_set_encoder_parts.restype = ci
         L.hfz_set_encoder_parts.argtypes = [ci]
+        L.hfz_set_decoder_parts.restype = ci
+        L.hfz_set_decoder_parts.argtypes = [ci]
         L.hfz_set_frames_per_wave.restype = ci
         L.hfz_set_frames_per_wave.argtypes = [ci]
         L.hfz_set_decoder_table_bits.restype = ci
@@ -455,6 +457,11 @@ def set_encoder_block(nbytes=0):
 def set_encoder_parts(n=0):
     """0 = automatic, 1 = one thread per stream, n = up to n threads per stream."""
     _check(lib().hfz_set_encoder_parts(int(n)), "hfz_set_encoder_parts")
+
+
+def set_decoder_parts(n=0):
+    """0 = automatic, 1 = one thread per stream, n = up to n threads per stream."""
+    _check(lib().hfz_set_decoder_parts(int(n)), "hfz_set_decoder_parts")
 
 
 def timing_enable(every=1):

@@ -517,6 +517,12 @@ int hfz_set_encoder_parts(int n) {
   return HFZ_OK;
 }
 
+int hfz_set_decoder_parts(int n) {
+  if (n < 0 || n > 64) return HFZ_E_ARG;
+  g_decoder_parts = n;
+  return HFZ_OK;
+}
+
 int hfz_set_decoder_store(int mode) {
   if (mode < 0 || mode > 2) return HFZ_E_ARG;
   g_decoder_store = mode;

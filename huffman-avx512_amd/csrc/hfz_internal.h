@@ -67,6 +67,8 @@ extern std::atomic<int> g_encoder_block;
 extern std::atomic<int> g_encoder_parts;
 // 0 = choose by batch size, 1 / 2 = forced (hfz_set_decoder_store).
 extern std::atomic<int> g_decoder_store;
+// 0 = choose by batch size, n = up to n threads per stream (hfz_set_decoder_parts).
+extern std::atomic<int> g_decoder_parts;
 
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);

@@ -1498,40 +1498,55 @@ __device__ __forceinline__ uint32_t table_free_entry(uint32_t c12, const uint32_
 //      of up to 2 KiB (128 KiB frames of 64 streams), 4-11 % slower with longer
 //      ones, where a line reaches memory in four pieces that are rounds apart
 //      instead of two and the lanes' lines crowd the same memory channels.
-template <uint32_t kDecTabBits, uint32_t kWaves, uint32_t kF, uint32_t kStore>
-__global__ __launch_bounds__(64 * kWaves) void decode_kernel(
+template <uint32_t kDecTabBits, uint32_t kWaves, uint32_t kF, uint32_t kStore, bool kParts, uint32_t kInBlk = kDecInBlk>
+__global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     uint32_t K, const uint8_t* __restrict__ comp, uint64_t comp_bytes,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
     uint64_t n_frames, uint8_t* __restrict__ raw, uint64_t raw_cap, uint64_t frame_bytes,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, uint32_t log2_parts) {
   static_assert(kF == 1 || (kF == 2 && kWaves == 1), "two frames per wave only without table sharing");
-  static_assert(kStore <= 2 && (kStore != 2 || (kF == 1 && kWaves == 1)), "pair stores: one frame per wave");
+  static_assert(kStore <= 2 && (kStore != 2 || (kF == 1 && kWaves == 1)), "pair stores: one frame per wave or workgroup");
   constexpr bool kPair64 = kStore == 1;
   constexpr bool kTableFree = kDecTabBits == 0;
+  // input ring per lane: two blocks of kInBlk bytes (64; 32 halves the ring at the
+  // price of staging twice as often)
+  static_assert(kInBlk == 32 || kInBlk == 64, "input blocks of 32 or 64 bytes");
+  constexpr uint32_t kInDw = kInBlk / 2;
+  constexpr uint32_t kBlkDw = kInBlk / 4;
   static_assert(!kTableFree || (kF == 1 && kWaves == 1), "table-free build: one frame per wave");
+  static_assert(!kParts || (kF == 1 && kWaves == 1 && kStore != 1 && !kTableFree), "parts: one frame per workgroup");
   // table-free: words 0..12 first code | first symbol index << 16 per length, bytes 64.. the symbol list
   __shared__ uint32_t tab[kTableFree ? 16 + 64 : (kF << kDecTabBits)];
   uint32_t fend[kMaxCodeLen];  // table-free: first code beyond every length below 12 (wave-uniform)
 #pragma unroll
   for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = 0;
-  __shared__ uint32_t ringmem[kWaves * 64 * (kDecInDw + kDecOutDw)];
+  // one pair of rings per wave; with parts the launch sizes them (dynamic LDS)
+  __shared__ uint32_t ringmem_one[kParts ? 1 : kWaves * 64 * (kInDw + kDecOutDw)];
+  extern __shared__ uint32_t ringmem_dyn[];
+  uint32_t* const ringmem = kParts ? ringmem_dyn : ringmem_one;
+  // parts: the length of the first code under every table index stays alive next to the table
+  __shared__ uint8_t l1keep[kParts ? (1u << kDecTabBits) : 4];
+  __shared__ uint32_t cls_keep[kParts ? 16 : 1];
+  __shared__ int wg_bad;  // parts: some thread of the workgroup found its stream corrupt
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
-  const uint32_t wave = kWaves == 1 ? 0 : tid >> 6;
+  const uint32_t wave = (kWaves == 1 && !kParts) ? 0 : tid >> 6;
+  const uint32_t n_threads = kParts ? blockDim.x : 64 * kWaves;
   const uint32_t half = kF == 1 ? 0 : lane >> 5;
-  const uint32_t k = kF == 1 ? lane : lane & 31;  // stream index within the frame
-  uint32_t* const iring = ringmem + wave * 64 * (kDecInDw + kDecOutDw);
-  uint32_t* const obuf_all = iring + 64 * kDecInDw;
+  // stream index within the frame (parts: thread t is part t % P of stream t / P)
+  const uint32_t k = kParts ? tid >> log2_parts : (kF == 1 ? lane : lane & 31);
+  uint32_t* const iring = ringmem + wave * 64 * (kInDw + kDecOutDw);
+  uint32_t* const obuf_all = iring + 64 * kInDw;
   // scratch that is only live while a table is built (on the first wave's input
   // rings): the length of the first code under every (reversed) table index
-  uint8_t* const l1tab = (uint8_t*)ringmem;
-  static_assert(sizeof(uint32_t) * 64 * kDecInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
+  uint8_t* const l1tab = kParts ? l1keep : (uint8_t*)ringmem;
+  static_assert(kParts || sizeof(uint32_t) * 64 * kInDw >= (1u << kDecTabBits), "l1tab fits in the input rings");
   static_assert(64 * kDecOutDw >= 192, "header staging fits in the output rows");
   STAMP_DECL();
-#define HFZ_BARRIER()                 \
-  do {                                \
-    if (kWaves == 1) wave_sync();     \
-    else __syncthreads();             \
+#define HFZ_BARRIER()                           \
+  do {                                          \
+    if (kWaves == 1 && !kParts) wave_sync();    \
+    else __syncthreads();                       \
   } while (0)
 
   // what a lane keeps of its frame
@@ -1540,11 +1555,14 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   int err = HFZ_OK;
   const uint8_t* in = comp;
   uint32_t raw_size = 0, hdr_total = 0, end = kSlop;
+  uint32_t begin_k = 0;      // parts: where this thread's stream begins in the stream area
+  bool multi_symbol = false;  // parts: the code has at least two symbols (every code has a bit)
+  if (kParts && tid == 0) wg_bad = 0;
 
 #pragma unroll
   for (uint32_t pass = 0; pass < kF; ++pass) {
     const bool mine = kF == 1 || half == pass;
-    const uint64_t pf = ((uint64_t)blockIdx.x * kWaves + wave) * kF + pass;
+    const uint64_t pf = kParts ? (uint64_t)blockIdx.x : ((uint64_t)blockIdx.x * kWaves + wave) * kF + pass;
     // The frame's header: one round trip brings all of it (at most 8 + 13 + 256
     // + 4*63 bytes) into LDS; everything below parses it there.
     const bool p_present = pf < n_frames;
@@ -1579,7 +1597,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     // read from the workgroup's first frame, which is this frame when kWaves = 1.
     // ParseCompressedHeader (codec/huffman.cpp:714-736) + canonical code starts
     // (ForallCodes, codec/huffman.cpp:260-284).
-    const uint32_t* const lead = ringmem + 64 * kDecInDw;
+    const uint32_t* const lead = ringmem + 64 * kInDw;
     const uint8_t* const hb = (const uint8_t*)lead;
     const uint32_t len_mask = lead[1];
     const uint32_t nlen = __popc(len_mask);
@@ -1605,7 +1623,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     if (nsym > 256) lead_err = HFZ_E_CORRUPT;
     if (nsym == 0 ? lead_raw_size != 0 : cur != (1u << kMaxCodeLen)) lead_err = HFZ_E_CORRUPT;
     if (kF == 1 && lead_err != HFZ_OK) {  // uniform over the workgroup: nobody waits at a barrier below
-      if (lane == 0 && status && p_present) status[pf] = p_err != HFZ_OK ? p_err : lead_err;
+      if ((kParts ? tid : lane) == 0 && status && p_present) status[pf] = p_err != HFZ_OK ? p_err : lead_err;
       return;
     }
     if (p_err == HFZ_OK) p_err = lead_err;
@@ -1637,27 +1655,46 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     // stream boundaries (codec/huffman.cpp:897-901); lanes without a stream get an empty one
     const uint32_t area_size = p_err == HFZ_OK ? size - p_hdr_total : 0;
     uint32_t p_end = kSlop;
+    uint32_t p_begin = 0;
     if (p_err == HFZ_OK) {
+      const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
+      // the stream between end offsets kk - 1 and kk; *bad_: it does not fit the area or its slop
+#define HFZ_STREAM_BOUNDS(kk, begin_, end_, bad_)                                             \
+  do {                                                                                        \
+    if ((kk) < K - 1) {                                                                       \
+      const uint32_t q_ = eo + 4 * (kk);                                                      \
+      end_ = __builtin_amdgcn_alignbyte(hdrw[(q_ >> 2) + 1], hdrw[q_ >> 2], q_ & 3);          \
+    } else {                                                                                  \
+      end_ = area_size;                                                                       \
+    }                                                                                         \
+    if (kk) {                                                                                 \
+      const uint32_t q_ = eo + 4 * ((kk) - 1);                                                \
+      begin_ = __builtin_amdgcn_alignbyte(hdrw[(q_ >> 2) + 1], hdrw[q_ >> 2], q_ & 3);        \
+    }                                                                                         \
+    bad_ = end_ > area_size || begin_ > end_ || end_ - begin_ < (uint32_t)kSlop;              \
+  } while (0)
       bool bad = false;
-      if (mine && k < K) {
-        uint32_t begin = 0;
-        const uint32_t eo = 8 + nlen + nsym;  // byte offset of the end-offset array
-        if (k < K - 1) {
-          const uint32_t q = eo + 4 * k;
-          p_end = __builtin_amdgcn_alignbyte(hdrw[(q >> 2) + 1], hdrw[q >> 2], q & 3);
-        } else {
-          p_end = area_size;
+      if (kParts) {
+        // every wave checks all streams (lane l: stream l), so that the verdict is the
+        // same in every wave and the workgroup leaves, or stays, together
+        if (lane < K) {
+          uint32_t b0 = 0, e0 = kSlop;
+          HFZ_STREAM_BOUNDS(lane, b0, e0, bad);
         }
-        if (k) {
-          const uint32_t q = eo + 4 * (k - 1);
-          begin = __builtin_amdgcn_alignbyte(hdrw[(q >> 2) + 1], hdrw[q >> 2], q & 3);
+        bad = __any(bad);
+        if (!bad && k < K) {
+          bool mine_bad;
+          HFZ_STREAM_BOUNDS(k, p_begin, p_end, mine_bad);
+          (void)mine_bad;
         }
-        bad = p_end > area_size || begin > p_end || p_end - begin < (uint32_t)kSlop;
+      } else if (mine && k < K) {
+        HFZ_STREAM_BOUNDS(k, p_begin, p_end, bad);
       }
+#undef HFZ_STREAM_BOUNDS
       if (__any(bad)) p_err = HFZ_E_CORRUPT;
     }
     if (kWaves == 1 && kF == 1 && p_err != HFZ_OK) {
-      if (lane == 0 && status && p_present) status[pf] = p_err;
+      if ((kParts ? tid : lane) == 0 && status && p_present) status[pf] = p_err;
       return;
     }
     if (mine) {
@@ -1668,6 +1705,8 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
       raw_size = p_raw_size;
       hdr_total = p_hdr_total;
       end = p_end;
+      begin_k = p_begin;
+      multi_symbol = nsym >= 2;
     }
     STAMP(0);  // header
 
@@ -1683,7 +1722,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     uint32_t* const ptab = tab + (pass << kDecTabBits);
     constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
     static_assert(kTabShift <= 1, "sibling entries cover one bit");
-    uint32_t* const cls = ringmem + 1024;  // behind l1tab (at most 4096 bytes)
+    uint32_t* const cls = kParts ? cls_keep : ringmem + 1024;  // behind l1tab (at most 4096 bytes)
     if (kTableFree) {
 #pragma unroll
       for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = __builtin_amdgcn_readfirstlane(fcode[l + 1]);
@@ -1700,7 +1739,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     HFZ_BARRIER();
     if (!kTableFree && (kF == 1 || p_err == HFZ_OK)) {
 #pragma unroll 4
-      for (uint32_t r = tid; r < (1u << kDecTabBits); r += 64 * kWaves) {
+      for (uint32_t r = tid; r < (1u << kDecTabBits); r += n_threads) {
         const uint32_t c12 = (__builtin_bitreverse32(r) >> (32 - (kTableFree ? 1 : kDecTabBits))) << kTabShift;
         uint32_t L = 0;
 #pragma unroll
@@ -1725,7 +1764,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     // while it is being rewritten is safe.
     if (!kTableFree && (kF == 1 || p_err == HFZ_OK)) {
 #pragma unroll 8
-      for (uint32_t r = tid; r < (1u << kDecTabBits); r += 64 * kWaves) {
+      for (uint32_t r = tid; r < (1u << kDecTabBits); r += n_threads) {
         const uint32_t L1 = l1tab[r];
         const uint32_t rr = r >> L1;
         const uint32_t L2 = l1tab[rr];
@@ -1762,8 +1801,11 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   s.begin = 0;
   s.size = 0;
   if (k < K) s = slice_of(raw_size, K, k);
-  const uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
-  const uint32_t out_hi = out_lo + s.size;
+  // the bytes this thread produces: its stream's slice, or with parts a piece of it (set below)
+  uint32_t out_lo = (uint32_t)((uintptr_t)frame_out - (uintptr_t)obase) + s.begin;
+  uint32_t out_hi = out_lo + s.size;
+  int32_t left = (int32_t)s.size;  // symbols still to produce; a round may overshoot below zero
+  bool stream_bad = false;
 
   uint32_t* const irow = iring + lane;      // row r of this lane's input ring: irow[64 * r]
   uint32_t* const orow32 = obuf_all + lane;  // dword d of its output ring: orow32[64 * d]
@@ -1775,32 +1817,22 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #define HFZ_LOAD_BLOCK(blk)                                       \
   do {                                                            \
     if ((int64_t)(int32_t)(blk) >= min_off) {                     \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)            \
+      _Pragma("unroll") for (int q_ = 0; q_ < (int)(kInBlk / 16); ++q_) \
         pre[q_] = *(const uint4*)(cbase + (blk) + 16 * q_);       \
     }                                                             \
   } while (0)
   // writes the registers, every dword bit-reversed, into the ring rows of block
-  // `blk`: dword j of the block goes to row (blk & 64 ? 0 : 16) + 15 - j
+  // `blk`: dword j of a block of n dwords goes to row (blk & 4n ? 0 : n) + n - 1 - j
 #define HFZ_STAGE_BLOCK(blk)                                      \
   do {                                                            \
-    uint32_t* d_ = irow + 64 * (((blk) & kDecInBlk) ? 0 : 16);    \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {            \
-      d_[64 * (15 - 4 * q_)] = __builtin_bitreverse32(pre[q_].x); \
-      d_[64 * (14 - 4 * q_)] = __builtin_bitreverse32(pre[q_].y); \
-      d_[64 * (13 - 4 * q_)] = __builtin_bitreverse32(pre[q_].z); \
-      d_[64 * (12 - 4 * q_)] = __builtin_bitreverse32(pre[q_].w); \
+    uint32_t* d_ = irow + 64 * (((blk) & kInBlk) ? 0 : kBlkDw);   \
+    _Pragma("unroll") for (int q_ = 0; q_ < (int)(kInBlk / 16); ++q_) { \
+      d_[64 * ((int)kBlkDw - 1 - 4 * q_)] = __builtin_bitreverse32(pre[q_].x); \
+      d_[64 * ((int)kBlkDw - 2 - 4 * q_)] = __builtin_bitreverse32(pre[q_].y); \
+      d_[64 * ((int)kBlkDw - 3 - 4 * q_)] = __builtin_bitreverse32(pre[q_].z); \
+      d_[64 * ((int)kBlkDw - 4 - 4 * q_)] = __builtin_bitreverse32(pre[q_].w); \
     }                                                             \
   } while (0)
-
-  // prime the ring with the two blocks below the stream end, start the third
-  uint32_t low_blk = (g_end - 1) & ~(kDecInBlk - 1);  // lowest block staged so far
-  HFZ_LOAD_BLOCK(low_blk);
-  HFZ_STAGE_BLOCK(low_blk);
-  low_blk -= kDecInBlk;
-  HFZ_LOAD_BLOCK(low_blk);
-  HFZ_STAGE_BLOCK(low_blk);
-  HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
-  STAMP(2);  // priming
 
   // Bit reader (CodeReader, codec/huffman.cpp:502-586).  wlo and whi are the
   // (reversed) dwords under the bit position, wlo the one being consumed; wnx
@@ -1814,18 +1846,11 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   // ra = 256 * (ring row of wnx), running on without wrapping; ra_low the same
   // for the lowest staged dword, so ra_low - ra = 256 * (staged dwords below
   // wnx); ra_area for the dword holding the first byte of the stream area.
-  const uint32_t d_last = (g_end - 1) >> 2;  // dword holding the stream's last byte
-  uint32_t ra = (31u - (d_last - 1)) << 8;
-  uint32_t ra_low = (31u - (low_blk >> 2)) << 8;
+  uint32_t low_blk = 0;  // lowest block staged so far
+  uint32_t ra = 0, ra_low = 0, wlo = 0, whi = 0, wnx = 0, sacc = 0;
   const uint32_t ra_area = (31u - (area_off >> 2)) << 8;
   const uint8_t* const icol = (const uint8_t*)irow;
-  constexpr uint32_t kInRowMask = (kDecInDw - 1) << 8;
-  // start one dword up: the bytes of d_last above the stream end and the whole
-  // dword above it count as consumed, and the first refill moves down
-  uint32_t wlo = *(const uint32_t*)(icol + ((ra - 512) & kInRowMask));
-  uint32_t whi = *(const uint32_t*)(icol + ((ra - 256) & kInRowMask));
-  uint32_t wnx = *(const uint32_t*)(icol + (ra & kInRowMask));
-  uint32_t sacc = 32 + 8 * (3 - ((g_end - 1) & 3)) - 2;
+  constexpr uint32_t kInRowMask = (kInDw - 1) << 8;
   // after a pair: wlo used up -> whi:wlo <- wnx:whi, and the next wnx is read
 #define HFZ_REFILL()                                                         \
   do {                                                                       \
@@ -1836,7 +1861,188 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     sacc &= 31;                                                              \
     wnx = *(const uint32_t*)(icol + (ra & kInRowMask));                      \
   } while (0)
-  HFZ_REFILL();
+  // Puts the reader at bit bp_ of the stream (0 = its first bit, the top bit of
+  // its last byte): primes the ring with the two blocks below that byte and starts
+  // loading the third; then one dword up: the bytes of the dword above the
+  // position, the whole dword above that one and the bp_ & 7 bits of the byte
+  // itself count as consumed, and the first refill moves down.
+#define HFZ_READER_AT(bp_)                                                   \
+  do {                                                                       \
+    const uint32_t ge_ = g_end - ((bp_) >> 3); /* one past the byte holding the bit */ \
+    low_blk = (ge_ - 1) & ~(kInBlk - 1);                                     \
+    HFZ_LOAD_BLOCK(low_blk);                                                 \
+    HFZ_STAGE_BLOCK(low_blk);                                                \
+    low_blk -= kInBlk;                                                       \
+    HFZ_LOAD_BLOCK(low_blk);                                                 \
+    HFZ_STAGE_BLOCK(low_blk);                                                \
+    HFZ_LOAD_BLOCK(low_blk - kInBlk);                                        \
+    const uint32_t d_last_ = (ge_ - 1) >> 2; /* dword holding that byte */   \
+    ra = (31u - (d_last_ - 1)) << 8;                                         \
+    ra_low = (31u - (low_blk >> 2)) << 8;                                    \
+    wlo = *(const uint32_t*)(icol + ((ra - 512) & kInRowMask));              \
+    whi = *(const uint32_t*)(icol + ((ra - 256) & kInRowMask));              \
+    wnx = *(const uint32_t*)(icol + (ra & kInRowMask));                      \
+    sacc = 32 + 8 * (3 - ((ge_ - 1) & 3)) - 2 + ((bp_) & 7);                 \
+    HFZ_REFILL();                                                            \
+  } while (0)
+  // the entry for the code at the bottom of window t_ (bits 2..)
+#define HFZ_ENTRY(t_)                                                                           \
+  (kTableFree ? table_free_entry(__builtin_bitreverse32((t_) >> 2) >> 20, fend, tab)            \
+              : *(const uint32_t*)(tabb + ((t_) & kTabMask)))
+  // A round moves the reader down by at most kDecRoundDw dwords and its last
+  // refill reads the dword below: a lane can run a round when that many dwords
+  // below wnx are staged.
+  constexpr int32_t kReach = (int32_t)(kDecRoundDw << 8);
+
+  uint32_t start_bit = 0;  // where this thread starts reading its stream
+  if (kParts) {
+    // Several threads per stream.  A stream is one chain of codes with no marks
+    // in it, but a decoder that starts at a wrong bit falls into step with the
+    // true code boundaries after a few codes (a Huffman code synchronises
+    // itself), so: the stream's bits are cut into P pieces of equal length;
+    // thread p starts kGuard bits before its piece, takes the first code boundary
+    // it reaches at or beyond the piece's start as its start s_p, and decodes on
+    // (counting symbols, writing nothing) to the first boundary e_p at or beyond
+    // the next piece's start.  If e_(p-1) = s_p for every p, all starts are true
+    // boundaries (thread 0's is, and each thread hands a boundary of its own chain
+    // to the next); a thread whose start is not what its neighbour reached starts
+    // again from there, until nothing changes (at most P times, once in practice).
+    // A prefix sum of the counts places every piece in the output, and the
+    // pieces are decoded like streams of their own.  Same bytes as one lane per
+    // stream (codec/huffman.cpp:931-953).
+    const uint32_t P = 1u << log2_parts;
+    const uint32_t part = tid & (P - 1);
+    // far enough for text-like codes to fall into step all but once in a few thousand
+    // starts (skewed codes do so within 64 bits)
+    constexpr uint32_t kGuard = 256;
+    // bits of the stream, rounded up to whole bytes; a code without bits (a frame
+    // of one symbol) gives nothing to cut: everything goes to the last part
+    const uint32_t total_bits = (multi_symbol && k < K && s.size) ? 8 * (end - begin_k - (uint32_t)kSlop) : 0;
+    const uint32_t piece = (total_bits + P - 1) >> log2_parts;
+    const uint32_t b_lo = part * piece < total_bits ? part * piece : total_bits;
+    const uint32_t b_hi = (part + 1) * piece < total_bits ? (part + 1) * piece : total_bits;
+    const bool last_part = part == P - 1;
+    uint32_t s_bit = 0, e_bit = 0, n_sym = 0;
+    for (uint32_t iter = 0; iter <= P; ++iter) {
+      // this pass: start at bit x; while in_pre run to tgt = b_lo without counting
+      // (that boundary becomes s_bit), then count up to b_hi
+      uint32_t x, tgt;
+      bool in_pre = false, run;
+      if (iter == 0) {
+        run = true;
+        in_pre = part != 0;
+        x = in_pre ? (b_lo > kGuard ? b_lo - kGuard : 0) : 0;
+        tgt = in_pre ? b_lo : b_hi;
+      } else {
+        const uint32_t prev_e = (uint32_t)__shfl_up((int)e_bit, 1, (int)P);
+        run = part != 0 && prev_e != s_bit;
+        if (!__any(run)) break;
+        if (run) s_bit = prev_e;
+        x = s_bit;
+        tgt = last_part ? x : b_hi;  // the last part only needs its start
+      }
+      if (in_pre && x >= tgt) {  // nothing to skip: the piece starts the stream or lies beyond its end
+        s_bit = x;
+        in_pre = false;
+        tgt = last_part ? x : b_hi;
+      }
+      uint32_t n = 0;
+      bool active = run && x < tgt;
+      if (__any(active)) {
+        if (active) HFZ_READER_AT(x);
+        for (;;) {
+          if (!__any(active)) break;
+          if (active && (int32_t)(ra_low - ra) < kReach) {  // out of staged input: next block
+            if ((int32_t)(ra_low - ra_area) >= kReach) {    // see the decoding loop below
+              stream_bad = true;
+              active = false;
+            } else {
+              low_blk -= kInBlk;
+              ra_low += kBlkDw << 8;
+              HFZ_STAGE_BLOCK(low_blk);
+              HFZ_LOAD_BLOCK(low_blk - kInBlk);
+            }
+          }
+          for (;;) {
+            const bool can = active && (int32_t)(ra_low - ra) >= kReach;
+            if (!__any(can)) break;
+            if (can) {
+              if (tgt - x > kDecRound * (uint32_t)kMaxCodeLen) {
+                // far from the target: a round of lookups as in the decoding loop, minus the output
+                const uint32_t ra_b = ra, sacc_b = sacc;
+                uint32_t cnt = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kDecRound / 2; ++j) {
+                  const uint64_t win = ((uint64_t)whi << 32) | wlo;
+                  const uint32_t e1 = HFZ_ENTRY((uint32_t)(win >> (sacc & 63)));
+                  sacc += e1;
+                  const uint32_t e2 = HFZ_ENTRY((uint32_t)(win >> (sacc & 63)));
+                  sacc += e2;
+                  cnt += (e1 & 0x1800u) + (e2 & 0x1800u);  // 8 * symbols sits in byte 1
+                  HFZ_REFILL();
+                }
+                x += ((ra - ra_b) >> 3) + sacc - sacc_b;  // 256 per dword = 8 per bit
+                n += cnt >> 11;
+              } else {
+                // near the target: an entry is taken whole while even its last bit lies
+                // before the target (then so does the boundary between its two codes);
+                // else one code at a time
+#pragma unroll 4
+                for (uint32_t j = 0; j < kDecRound; ++j) {
+                  const uint64_t win = ((uint64_t)whi << 32) | wlo;
+                  const uint32_t t = (uint32_t)(win >> (sacc & 63));
+                  const uint32_t e = HFZ_ENTRY(t);
+                  uint32_t bits = e & 0xffu, syms = (e >> 11) & 3u;
+                  const bool go = x < tgt;
+                  if (__any(go && x + bits > tgt)) {
+                    const uint32_t l1 = l1tab[(t & kTabMask) >> 2];
+                    if (x + bits > tgt) {
+                      bits = l1;
+                      syms = 1;
+                    }
+                  }
+                  bits = go ? bits : 0;
+                  syms = go ? syms : 0;
+                  sacc += bits;
+                  x += bits;
+                  n += syms;
+                  HFZ_REFILL();
+                }
+              }
+              if (in_pre && x >= tgt) {  // reached the piece: this boundary is the start
+                s_bit = x;
+                n = 0;
+                in_pre = false;
+                tgt = last_part ? x : b_hi;
+              }
+              active = x < tgt;
+            }
+          }
+        }
+      }
+      if (run) {
+        e_bit = x;
+        n_sym = n;
+      }
+    }
+    // place the pieces: symbols before this one, clamped to the slice (a piece that
+    // reads past the end of a stream counts padding bits as codes)
+    uint32_t incl = last_part ? 0u : n_sym;
+    for (uint32_t d = 1; d < P; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)d, (int)P);
+      if (part >= d) incl += o;
+    }
+    uint32_t before = incl - (last_part ? 0u : n_sym);
+    before = before < s.size ? before : s.size;
+    uint32_t mine_n = last_part ? s.size - before : n_sym;
+    if (mine_n > s.size - before) mine_n = s.size - before;
+    out_lo += before;
+    out_hi = out_lo + mine_n;
+    left = (int32_t)mine_n;
+    start_bit = s_bit;
+  }
+  if (!kParts || left > 0) HFZ_READER_AT(start_bit);
+  STAMP(2);  // priming
 
   // output: decoded bytes collect in ocur (sh = 8 * their number, < 32 between
   // pairs); wp is the output offset of the dword being filled.  That
@@ -1853,8 +2059,6 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   constexpr uint32_t kOutRowMask = (kDecOutDw - 1) << 8;
   uint32_t wa = ((wp >> 2) & (kDecOutDw - 1)) << 8;
   uint32_t nfb = out_lo & ~(kDecBlk - 1);
-  int32_t left = (int32_t)s.size;  // symbols still to produce; a round may overshoot below zero
-  bool stream_bad = false;
   uint32_t sb[8];   // the block at sb_at; with kPair64 the even block of a pair
   uint32_t sb_at = 0;
   bool sb_full = false;
@@ -1862,11 +2066,7 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
   uint32_t sc_at = 0;
   bool sc_full = false;
 
-  // the entry for the code at the bottom of window t_ (bits 2..)
-#define HFZ_ENTRY(t_)                                                                           \
-  (kTableFree ? table_free_entry(__builtin_bitreverse32((t_) >> 2) >> 20, fend, tab)            \
-              : *(const uint32_t*)(tabb + ((t_) & kTabMask)))
-  // its symbols, w_ = 8 * their number (in bits 0..4; v_bfe_u32 looks no further).
+  // the symbols of an entry, w_ = 8 * their number (in bits 0..4; v_bfe_u32 looks no further).
   // 11-bit table: offset 24 instead of 16 iff the entry counts one symbol (bit 3
   // of w_) and the 12th bit of the code (bit 13 of t_) is set.
 #define HFZ_SYMS(e_, t_, w_)                                                                    \
@@ -1932,10 +2132,6 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
     }                                                                        \
   } while (0)
 
-  // A round moves the reader down by at most kDecRoundDw dwords and its last
-  // refill reads the dword below: a lane can run a round when that many dwords
-  // below wnx are staged.
-  constexpr int32_t kReach = (int32_t)(kDecRoundDw << 8);
   for (;;) {
     if (!__any(left > 0)) break;
     if (left > 0 && (int32_t)(ra_low - ra) < kReach) {  // out of staged input: next block
@@ -1946,10 +2142,10 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
         stream_bad = true;
         left = 0;
       } else {
-        low_blk -= kDecInBlk;
-        ra_low += (kDecInBlk / 4) << 8;
+        low_blk -= kInBlk;
+        ra_low += kBlkDw << 8;
         HFZ_STAGE_BLOCK(low_blk);
-        HFZ_LOAD_BLOCK(low_blk - kDecInBlk);
+        HFZ_LOAD_BLOCK(low_blk - kInBlk);
       }
     }
     STAMP(3);  // staging
@@ -2060,6 +2256,12 @@ __global__ __launch_bounds__(64 * kWaves) void decode_kernel(
 #undef HFZ_STAGE_BLOCK
   STAMP(7);  // tail
   STAMP_FLUSH(0);
+  if (kParts) {  // the verdict of all waves of the frame
+    if (__ballot(stream_bad) != 0 && lane == 0) atomicOr(&wg_bad, 1);
+    __syncthreads();
+    if (tid == 0 && status) status[f] = wg_bad ? HFZ_E_CORRUPT : HFZ_OK;
+    return;
+  }
   if (status) {
     const uint64_t bad_lanes = __ballot(stream_bad);
     const bool any_bad = kF == 1 ? bad_lanes != 0 : ((bad_lanes >> (32 * half)) & 0xffffffffull) != 0;
@@ -2125,6 +2327,7 @@ std::atomic<int> g_frames_per_wave{0};
 std::atomic<int> g_encoder_block{0};
 std::atomic<int> g_encoder_parts{0};
 std::atomic<int> g_decoder_store{0};
+std::atomic<int> g_decoder_parts{0};
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -2276,6 +2479,31 @@ uint32_t encoder_log2_parts(int K, uint64_t n_frames, uint64_t frame_bytes) {
   return l;
 }
 
+// Threads per stream (as a power of two) in the decoder: none once one wave per
+// frame fills the chip, else as many as it takes to get there, within 512
+// threads per frame, the parts of a stream inside one wave, and no less than 256
+// bytes of output per part.
+uint32_t decoder_log2_parts(int K, uint64_t n_frames, uint64_t frame_bytes) {
+  const int forced = g_decoder_parts.load(std::memory_order_relaxed);
+  uint32_t max_log2 = 0;
+  while (max_log2 < 6 && ((uint64_t)K << (max_log2 + 1)) <= 512) ++max_log2;
+  if (forced > 0) {
+    uint32_t l = 0;
+    while ((2u << l) <= (uint32_t)forced) ++l;
+    return l < max_log2 ? l : max_log2;
+  }
+  // Finding the pieces costs a pass of its own (about half a decoding pass), so two
+  // threads per stream never pay: parts only where at least four still leave the
+  // chip with no more than its eight waves per CU (a CU's LDS pipe is busy with
+  // eight; more waves on it do not decode faster).
+  const uint64_t want_threads = 8ull * 64 * (uint64_t)device_cus();
+  uint32_t l = 0;
+  while (l < max_log2 && (n_frames * (uint64_t)K << (l + 1)) <= want_threads &&
+         frame_bytes / ((uint64_t)K << (l + 1)) >= 256)
+    ++l;
+  return l >= 2 ? l : 0;
+}
+
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
@@ -2336,6 +2564,56 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
                   const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  // 12-bit table (28 KiB of LDS, 5 frames per CU) while that holds every frame
+  // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose 12th-bit pick
+  // costs less than the extra resident waves return.
+  const int cus = device_cus();
+  const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
+#define HFZ_LAUNCH_DECODE(BITS, WAVES, F, STORE)                                                  \
+  HFZ_LAUNCH(span, (decode_kernel<BITS, WAVES, F, STORE, false>), dim3((uint32_t)((n_frames + F - 1) / F)), \
+             dim3(64 * WAVES), 0, as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off,  \
+             d_comp_size, n_frames, d_raw, raw_cap, frame_bytes, d_status, 0u)
+  if (tab_bits == HFZ_DECODER_TABLE_FREE) {
+    // only on request (tests, comparison): one symbol per step, no lookup table
+    HFZ_LAUNCH_DECODE(0, 1, 1, 0);
+    return hipGetLastError();
+  }
+  // few frames: several threads per stream, one workgroup per frame
+  uint32_t log2_parts = decoder_log2_parts(K, n_frames, frame_bytes);
+  uint32_t threads = 64;
+  size_t ring_bytes = 0;
+  for (;; --log2_parts) {
+    threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
+    ring_bytes = (size_t)(threads / 64) * 64 * (kDecInDw + kDecOutDw) * sizeof(uint32_t);
+    if (log2_parts == 0 || ring_bytes + (24u << 10) <= device_lds_per_block()) break;
+  }
+  if (log2_parts) {
+#define HFZ_LAUNCH_DECODE_PARTS(BITS, STORE)                                                      \
+  do {                                                                                            \
+    if (ring_bytes > (40u << 10)) {                                                               \
+      hipError_t e_ = hipFuncSetAttribute((const void*)&decode_kernel<BITS, 1, 1, STORE, true>,   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                          (int)ring_bytes);                                       \
+      if (e_ != hipSuccess) return e_;                                                            \
+    }                                                                                             \
+    HFZ_LAUNCH(span, (decode_kernel<BITS, 1, 1, STORE, true>), dim3((uint32_t)n_frames),          \
+               dim3(threads), ring_bytes, as_stream(stream), (uint32_t)K, d_comp, comp_bytes,     \
+               d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes, d_status,          \
+               log2_parts);                                                                       \
+  } while (0)
+    // one table for all waves of the frame: the 12-bit one unless the other is asked
+    // for; lane pairs (neighbouring pieces of a stream) store together while a
+    // piece is short, as the lanes of short streams do
+    const int store = g_decoder_store.load(std::memory_order_relaxed);
+    const bool pair_store = store ? store == 2
+                                  : frame_bytes <= kPairStoreMaxSlice * ((uint64_t)K << log2_parts);
+    if (tab_bits == 11 && pair_store) HFZ_LAUNCH_DECODE_PARTS(11, 2);
+    else if (tab_bits == 11) HFZ_LAUNCH_DECODE_PARTS(11, 0);
+    else if (pair_store) HFZ_LAUNCH_DECODE_PARTS(12, 2);
+    else HFZ_LAUNCH_DECODE_PARTS(12, 0);
+#undef HFZ_LAUNCH_DECODE_PARTS
+    return hipGetLastError();
+  }
   if (shared_code && frame_bytes <= kSharedMaxFrame) {
     // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
     // LDS, three workgroups (nine frames) per CU and no sibling entries.  Pays
@@ -2343,46 +2621,27 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
     // frames go through the per-frame kernels below, which are faster there
     // (one-wave workgroups pack the CUs better) and decode any frame.
     const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
-    HFZ_LAUNCH(span, (decode_kernel<12, kSharedWaves, 1, 0>), dim3((uint32_t)groups),
+    HFZ_LAUNCH(span, (decode_kernel<12, kSharedWaves, 1, 0, false>), dim3((uint32_t)groups),
                        dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
                        comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
-                       d_status);
-    return hipGetLastError();
-  }
-  // 12-bit table (28 KiB of LDS, 5 frames per CU) while that holds every frame
-  // at once; beyond that the 11-bit one (20 KiB, 8 per CU), whose 12th-bit pick
-  // costs less than the extra resident waves return.
-  const int cus = device_cus();
-  const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
-  if (tab_bits == HFZ_DECODER_TABLE_FREE) {
-    // only on request (tests, comparison): one symbol per step, no lookup table
-    HFZ_LAUNCH(span, (decode_kernel<0, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
-                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+                       d_status, 0u);
     return hipGetLastError();
   }
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
-    HFZ_LAUNCH(span, (decode_kernel<11, 1, 2, 0>), dim3((uint32_t)((n_frames + 1) / 2)), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
-                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    HFZ_LAUNCH_DECODE(11, 1, 2, 0);
     return hipGetLastError();
   }
   const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
   if (wide)
-    HFZ_LAUNCH(span, (decode_kernel<12, 1, 1, 0>), dim3((uint32_t)n_frames), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
-                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    HFZ_LAUNCH_DECODE(12, 1, 1, 0);
   else if (g_decoder_store.load(std::memory_order_relaxed)
                ? g_decoder_store.load(std::memory_order_relaxed) == 2
                : frame_bytes <= kPairStoreMaxSlice * (uint64_t)K)
-    HFZ_LAUNCH(span, (decode_kernel<11, 1, 1, 2>), dim3((uint32_t)n_frames), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
-                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    HFZ_LAUNCH_DECODE(11, 1, 1, 2);
   else
-    HFZ_LAUNCH(span, (decode_kernel<11, 1, 1, 1>), dim3((uint32_t)n_frames), dim3(64), 0,
-                       as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size,
-                       n_frames, d_raw, raw_cap, frame_bytes, d_status);
+    HFZ_LAUNCH_DECODE(11, 1, 1, 1);
+#undef HFZ_LAUNCH_DECODE
   return hipGetLastError();
 }
 

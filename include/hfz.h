@@ -320,6 +320,24 @@ int hfz_set_encoder_block(int bytes);
 int hfz_set_encoder_parts(int n);
 
 /*
+ * Threads per stream in the decoder.  The reference hides the latency of a
+ * stream's chain of lookups behind the K streams of a frame
+ * (codec/huffman.cpp:931-948); one lane per stream gives a frame one wavefront
+ * whatever its size, so a batch of few frames (a single frame above all) leaves
+ * most of the chip idle.  With n > 1 every stream is decoded by n threads (a
+ * power of two, at most 512 / K and 64): the stream's bits are cut into n pieces,
+ * every thread finds a code boundary near the start of its piece by decoding
+ * from a little before it (a Huffman code falls into step by itself), neighbours
+ * check that each piece starts where the one before it ended and repeat from
+ * there if not, a prefix sum over the symbol counts places the pieces, and then
+ * each is decoded like a stream of its own.  n = 0 (default) picks by batch size:
+ * as many as it takes to occupy the chip, none for large batches; 1 = never;
+ * other values are rounded down to what K allows.  Decoded bytes are identical.
+ * Process-wide; no counterpart in the reference.
+ */
+int hfz_set_decoder_parts(int n);
+
+/*
  * How the one-frame-per-wave decoder with the 11-bit table writes its output:
  * mode = 1, every lane stores the blocks of its own stream, two 32-byte blocks
  * at a time (best for long streams); mode = 2, neighbouring lanes store each

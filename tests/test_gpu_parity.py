@@ -159,6 +159,71 @@ def test_encoder_parts_per_stream(torch_cuda, parts):
         hfz.set_encoder_block(0)
 
 
+@pytest.mark.parametrize("parts", [2, 8, 64])
+def test_decoder_parts_per_stream(torch_cuda, parts):
+    # several threads per stream in the decoder (chosen automatically for batches of
+    # few frames, which includes every single-frame call): force part counts over
+    # every reference case under both lookup tables, odd stream counts, streams
+    # shorter than the part count, batches, corrupt frames; decoded bytes must
+    # equal the input whatever the split
+    torch = torch_cuda
+    hfz.set_decoder_parts(parts)
+    try:
+        for bits in (12, 11):
+            hfz.set_decoder_table_bits(bits)
+            for name in CASE_FILES:
+                raw = load_input(name)
+                for K in tuple(KS) + (3, 7, 24, 40, 48, 63):
+                    assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (parts, bits, name, K)
+        hfz.set_decoder_table_bits(0)
+        for i, raw in enumerate(many_random()):
+            for K in (1, 2, 5, 32, 64):
+                assert hfz.decompress(K, oracle.compress(K, raw)) == raw, (parts, i, K)
+        sources = (geometric_cdf(), hfz.distributions.enwik_like_cdf(),
+                   hfz.distributions.cdf_from_weights([1000, 1] + [0] * 254),   # two symbols: 1-bit codes
+                   hfz.distributions.cdf_from_weights([1] * 256))               # 8-bit codes
+        for K, total, frame in ((64, (2 << 20) + 77, 256 << 10), (4, 1000003, 100 << 10), (33, 5000, 100),
+                                (8, 3 << 20, 1 << 20), (1, 70001, 70001), (16, 40000, 40000)):
+            for si, cdf in enumerate(sources):
+                data = hfz.generate(cdf, 21 + K + si, total)
+                codec = hfz.BatchCodec(K, total, frame)
+                batch = codec.compress(data)
+                out = codec.decompress(batch)
+                torch.cuda.synchronize()
+                assert int(codec.dstatus.abs().sum().item()) == 0, (parts, K, si)
+                assert torch.equal(out, data), (parts, K, si)
+        # frames of the oracle, one of them with a damaged stream and one cut short:
+        # refused or decoded to something, never a fault, and the good ones intact
+        K, frame_bytes = 8, 30000
+        raw = load_input("long_random.bin")[:4 * frame_bytes]
+        frames = [bytearray(oracle.compress(K, raw[i:i + frame_bytes])) for i in range(0, len(raw), frame_bytes)]
+        for i in range(len(frames[1]) - 200, len(frames[1]) - 100):
+            frames[1][i] ^= 0xa5
+        frames[2] = frames[2][:20]
+        blob, offs = bytearray(), []
+        for fr in frames:
+            offs.append(len(blob))
+            blob += fr
+        comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8), device="cuda")
+        d_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        d_size = torch.tensor([len(f) for f in frames], dtype=torch.int32, device="cuda")
+        out = torch.zeros(len(raw), dtype=torch.uint8, device="cuda")
+        status = torch.full((len(frames),), 77, dtype=torch.int32, device="cuda")
+        rc = hfz.lib().hfz_decompress_batch_dev(K, comp.data_ptr(), comp.numel(), d_off.data_ptr(),
+                                                d_size.data_ptr(), len(frames), out.data_ptr(),
+                                                len(raw), frame_bytes, status.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        st = status.cpu().tolist()
+        assert st[0] == 0 and st[3] == 0 and st[2] == hfz.HFZ_E_CORRUPT and st[1] in (0, hfz.HFZ_E_CORRUPT)
+        got = out.cpu().numpy().tobytes()
+        assert got[:frame_bytes] == raw[:frame_bytes]
+        assert got[3 * frame_bytes:] == raw[3 * frame_bytes:]
+    finally:
+        hfz.set_decoder_parts(0)
+        hfz.set_decoder_table_bits(0)
+
+
 def test_host_buffer_calls_from_several_threads(torch_cuda):
     # hfz_compress / hfz_decompress keep their device and pinned buffers in a pool;
     # concurrent callers must each get buffers of their own (ctypes drops the GIL
@@ -786,6 +851,7 @@ def test_random_batches_equal_oracle(torch_cuda):
             hfz.set_decoder_store(int(rng.choice([0, 1, 2])))
             hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
             hfz.set_encoder_block(int(rng.choice([0, 32, 64])))
+            hfz.set_decoder_parts(int(rng.choice([0, 1, 4, 16])))
             raw = hfz.generate(src, 1000 + case, total) if total else torch.empty(
                 0, dtype=torch.uint8, device="cuda")
             host = raw.cpu().numpy().tobytes()
@@ -805,3 +871,4 @@ def test_random_batches_equal_oracle(torch_cuda):
         hfz.set_decoder_store(0)
         hfz.set_frames_per_wave(0)
         hfz.set_encoder_block(0)
+        hfz.set_decoder_parts(0)
