@@ -42,6 +42,7 @@ EXPORTS = (
     "hfz_count_batch_dev", "hfz_compress_batch_counted_dev", "hfz_set_encoder_block",
     "hfz_static_workspace_init", "hfz_static_max_frames", "hfz_compress_batch_static_dev",
     "hfz_set_decoder_store", "hfz_set_encoder_parts", "hfz_set_decoder_parts",
+    "hfz_set_decoder_input_block",
 )
 
 
@@ -150,6 +151,8 @@ def lib():
         L.hfz_set_encoder_parts.argtypes = [ci]
         L.hfz_set_decoder_parts.restype = ci
         L.hfz_set_decoder_parts.argtypes = [ci]
+        L.hfz_set_decoder_input_block.restype = ci
+        L.hfz_set_decoder_input_block.argtypes = [ci]
         L.hfz_set_frames_per_wave.restype = ci
         L.hfz_set_frames_per_wave.argtypes = [ci]
         L.hfz_set_decoder_table_bits.restype = ci
@@ -462,6 +465,11 @@ def set_encoder_parts(n=0):
 def set_decoder_parts(n=0):
     """0 = automatic, 1 = one thread per stream, n = up to n threads per stream."""
     _check(lib().hfz_set_decoder_parts(int(n)), "hfz_set_decoder_parts")
+
+
+def set_decoder_input_block(nbytes=0):
+    """0 or 64 = 64-byte input blocks, 32 = 32-byte ones (11-bit-table decoder)."""
+    _check(lib().hfz_set_decoder_input_block(int(nbytes)), "hfz_set_decoder_input_block")
 
 
 def timing_enable(every=1):

@@ -523,6 +523,12 @@ int hfz_set_decoder_parts(int n) {
   return HFZ_OK;
 }
 
+int hfz_set_decoder_input_block(int bytes) {
+  if (bytes != 0 && bytes != 32 && bytes != 64) return HFZ_E_ARG;
+  g_decoder_input_block = bytes;
+  return HFZ_OK;
+}
+
 int hfz_set_decoder_store(int mode) {
   if (mode < 0 || mode > 2) return HFZ_E_ARG;
   g_decoder_store = mode;

@@ -69,6 +69,8 @@ extern std::atomic<int> g_encoder_parts;
 extern std::atomic<int> g_decoder_store;
 // 0 = choose by batch size, n = up to n threads per stream (hfz_set_decoder_parts).
 extern std::atomic<int> g_decoder_parts;
+// 0 / 64 = 64-byte input blocks, 32 = 32-byte ones (hfz_set_decoder_input_block).
+extern std::atomic<int> g_decoder_input_block;
 
 // Host-side canonical code construction (hfz_host.cpp).
 void build_frame_code(const uint32_t hist[256], FrameCode* out);

@@ -1722,7 +1722,10 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     uint32_t* const ptab = tab + (pass << kDecTabBits);
     constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
     static_assert(kTabShift <= 1, "sibling entries cover one bit");
-    uint32_t* const cls = kParts ? cls_keep : ringmem + 1024;  // behind l1tab (at most 4096 bytes)
+    // right behind l1tab, still inside the first wave's input ring (the header sits in its output ring)
+    uint32_t* const cls = kParts ? cls_keep : ringmem + (kTableFree ? 0 : (1u << kDecTabBits) / 4);
+    static_assert(kParts || kTableFree || sizeof(uint32_t) * 64 * kInDw >= (1u << kDecTabBits) + 64,
+                  "l1tab and the class list fit in the input ring");
     if (kTableFree) {
 #pragma unroll
       for (int l = 0; l < kMaxCodeLen; ++l) fend[l] = __builtin_amdgcn_readfirstlane(fcode[l + 1]);
@@ -2328,6 +2331,7 @@ std::atomic<int> g_encoder_block{0};
 std::atomic<int> g_encoder_parts{0};
 std::atomic<int> g_decoder_store{0};
 std::atomic<int> g_decoder_parts{0};
+std::atomic<int> g_decoder_input_block{0};
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -2569,13 +2573,31 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // costs less than the extra resident waves return.
   const int cus = device_cus();
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
-#define HFZ_LAUNCH_DECODE(BITS, WAVES, F, STORE)                                                  \
-  HFZ_LAUNCH(span, (decode_kernel<BITS, WAVES, F, STORE, false>), dim3((uint32_t)((n_frames + F - 1) / F)), \
-             dim3(64 * WAVES), 0, as_stream(stream), (uint32_t)K, d_comp, comp_bytes, d_comp_off,  \
-             d_comp_size, n_frames, d_raw, raw_cap, frame_bytes, d_status, 0u)
+#define HFZ_LAUNCH_DECODE_BLK(BITS, WAVES, F, STORE, BLK)                                         \
+  HFZ_LAUNCH(span, (decode_kernel<BITS, WAVES, F, STORE, false, BLK>),                            \
+             dim3((uint32_t)((n_frames + F - 1) / F)), dim3(64 * WAVES), 0, as_stream(stream),    \
+             (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap,  \
+             frame_bytes, d_status, 0u)
+#define HFZ_LAUNCH_DECODE(BITS, WAVES, F, STORE) HFZ_LAUNCH_DECODE_BLK(BITS, WAVES, F, STORE, 64)
+  // input blocks of 32 bytes (a 64-byte input ring per lane: 16 KiB of LDS per
+  // frame with the 11-bit table, ten frames per CU instead of eight) only on request
+  const bool small_blocks = g_decoder_input_block.load(std::memory_order_relaxed) == 32;
   if (tab_bits == HFZ_DECODER_TABLE_FREE) {
     // only on request (tests, comparison): one symbol per step, no lookup table
     HFZ_LAUNCH_DECODE(0, 1, 1, 0);
+    return hipGetLastError();
+  }
+  if (shared_code && frame_bytes <= kSharedMaxFrame) {
+    // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
+    // LDS, three workgroups (nine frames) per CU and no sibling entries.  Pays
+    // off while building a table is a visible part of a frame's work; larger
+    // frames go through the per-frame kernels below, which are faster there
+    // (one-wave workgroups pack the CUs better) and decode any frame.
+    const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
+    HFZ_LAUNCH(span, (decode_kernel<12, kSharedWaves, 1, 0, false>), dim3((uint32_t)groups),
+                       dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
+                       comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
+                       d_status, 0u);
     return hipGetLastError();
   }
   // few frames: several threads per stream, one workgroup per frame
@@ -2614,34 +2636,28 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
 #undef HFZ_LAUNCH_DECODE_PARTS
     return hipGetLastError();
   }
-  if (shared_code && frame_bytes <= kSharedMaxFrame) {
-    // one 12-bit table per workgroup of kSharedWaves frames: 16 + 3 * 12 KiB of
-    // LDS, three workgroups (nine frames) per CU and no sibling entries.  Pays
-    // off while building a table is a visible part of a frame's work; larger
-    // frames go through the per-frame kernels below, which are faster there
-    // (one-wave workgroups pack the CUs better) and decode any frame.
-    const uint64_t groups = (n_frames + kSharedWaves - 1) / kSharedWaves;
-    HFZ_LAUNCH(span, (decode_kernel<12, kSharedWaves, 1, 0, false>), dim3((uint32_t)groups),
-                       dim3(64 * kSharedWaves), 0, as_stream(stream), (uint32_t)K, d_comp,
-                       comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap, frame_bytes,
-                       d_status, 0u);
-    return hipGetLastError();
-  }
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
-    HFZ_LAUNCH_DECODE(11, 1, 2, 0);
+    if (small_blocks) HFZ_LAUNCH_DECODE_BLK(11, 1, 2, 0, 32);
+    else HFZ_LAUNCH_DECODE(11, 1, 2, 0);
     return hipGetLastError();
   }
   const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
+  const bool pair_store = g_decoder_store.load(std::memory_order_relaxed)
+                              ? g_decoder_store.load(std::memory_order_relaxed) == 2
+                              : frame_bytes <= kPairStoreMaxSlice * (uint64_t)K;
   if (wide)
     HFZ_LAUNCH_DECODE(12, 1, 1, 0);
-  else if (g_decoder_store.load(std::memory_order_relaxed)
-               ? g_decoder_store.load(std::memory_order_relaxed) == 2
-               : frame_bytes <= kPairStoreMaxSlice * (uint64_t)K)
+  else if (pair_store && small_blocks)
+    HFZ_LAUNCH_DECODE_BLK(11, 1, 1, 2, 32);
+  else if (pair_store)
     HFZ_LAUNCH_DECODE(11, 1, 1, 2);
+  else if (small_blocks)
+    HFZ_LAUNCH_DECODE_BLK(11, 1, 1, 1, 32);
   else
     HFZ_LAUNCH_DECODE(11, 1, 1, 1);
 #undef HFZ_LAUNCH_DECODE
+#undef HFZ_LAUNCH_DECODE_BLK
   return hipGetLastError();
 }
 

@@ -348,6 +348,15 @@ int hfz_set_decoder_parts(int n);
 int hfz_set_decoder_store(int mode);
 
 /*
+ * Bytes per block in which the 11-bit-table decoder fetches a stream: 64 (a
+ * 128-byte input ring per lane; default, also for bytes = 0) or 32 (a 64-byte
+ * ring: 4 KiB less LDS per wave, so more frames resident per CU, and twice as
+ * many staging steps; measured slower, kept for comparison).  Decoded bytes are
+ * identical.  Process-wide; no counterpart in the reference.
+ */
+int hfz_set_decoder_input_block(int bytes);
+
+/*
  * Deterministic integer-only synthetic source, filled on the device:
  * byte i = #{ j in [0,255) : cdf[j] <= u_i },  u_i = high 32 bits of
  * splitmix64(seed + (first_index + i + 1) * 0x9E3779B97F4A7C15).

@@ -83,13 +83,17 @@ def test_both_decoder_table_builds(torch_cuda, bits):
         hfz.set_decoder_table_bits(0)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_decoder_store_modes(torch_cuda, mode):
+@pytest.mark.parametrize("mode,block", [(1, 64), (2, 64), (1, 32), (2, 32)])
+def test_decoder_store_modes(torch_cuda, mode, block):
     # the 11-bit one-frame-per-wave decoder writes its output in one of two ways,
-    # chosen by batch size; force each one over every reference case and a batch
+    # chosen by batch size, and fetches its input in blocks of 64 bytes or (on
+    # request) 32; force each combination over every reference case and batches
+    # (one thread per stream: single frames would take several otherwise)
     torch = torch_cuda
     hfz.set_decoder_table_bits(11)
     hfz.set_decoder_store(mode)
+    hfz.set_decoder_input_block(block)
+    hfz.set_decoder_parts(1)
     try:
         for name in CASE_FILES:
             raw = load_input(name)
@@ -106,9 +110,21 @@ def test_decoder_store_modes(torch_cuda, mode):
             torch.cuda.synchronize()
             assert int(codec.dstatus.abs().sum().item()) == 0, (mode, K)
             assert torch.equal(out, data), (mode, K)
+        # two frames per wave take the block size as well
+        hfz.set_frames_per_wave(2)
+        for K, total, frame in ((32, 7 * 50000 + 1234, 50000), (5, 300000, 100000)):
+            data = hfz.generate(hfz.distributions.enwik_like_cdf(), 9 + K, total)
+            codec = hfz.BatchCodec(K, total, frame)
+            out = codec.decompress(codec.compress(data))
+            torch.cuda.synchronize()
+            assert int(codec.dstatus.abs().sum().item()) == 0, (mode, block, K)
+            assert torch.equal(out, data), (mode, block, K)
     finally:
         hfz.set_decoder_table_bits(0)
         hfz.set_decoder_store(0)
+        hfz.set_decoder_input_block(0)
+        hfz.set_decoder_parts(0)
+        hfz.set_frames_per_wave(0)
 
 
 def test_encoder_block_sizes(torch_cuda):
@@ -852,6 +868,7 @@ def test_random_batches_equal_oracle(torch_cuda):
             hfz.set_frames_per_wave(int(rng.choice([0, 1, 2])))
             hfz.set_encoder_block(int(rng.choice([0, 32, 64])))
             hfz.set_decoder_parts(int(rng.choice([0, 1, 4, 16])))
+            hfz.set_decoder_input_block(int(rng.choice([0, 32])))
             raw = hfz.generate(src, 1000 + case, total) if total else torch.empty(
                 0, dtype=torch.uint8, device="cuda")
             host = raw.cpu().numpy().tobytes()
@@ -872,3 +889,4 @@ def test_random_batches_equal_oracle(torch_cuda):
         hfz.set_frames_per_wave(0)
         hfz.set_encoder_block(0)
         hfz.set_decoder_parts(0)
+        hfz.set_decoder_input_block(0)
