@@ -907,13 +907,13 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
 // the byte values that occur (nonzero histogram bins), packed in ascending order.
 // Lane l walks the packed rows of parity l / 32 and owns counter word l % 32.
 // given != null: no code is built; the sizes are those under given[f * given_step].
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void code_sizes_kernel(uint32_t K, const uint32_t* __restrict__ hist,
-                                                        const uint32_t* __restrict__ counts,
-                                                        FrameCode* __restrict__ code,
-                                                        const FrameCode* __restrict__ given,
-                                                        uint32_t given_step,
-                                                        uint32_t* __restrict__ stream_end,
-                                                        uint32_t* __restrict__ csize) {
+__device__ __forceinline__ void code_sizes_body(uint32_t K, const uint32_t* __restrict__ hist,
+                                                const uint32_t* __restrict__ counts,
+                                                FrameCode* __restrict__ code,
+                                                const FrameCode* __restrict__ given,
+                                                uint32_t given_step,
+                                                uint32_t* __restrict__ stream_end,
+                                                uint32_t* __restrict__ csize) {
   __shared__ uint32_t lens[256];
   __shared__ uint32_t row_len[256];  // code length of the byte value of packed row j
   __shared__ uint32_t sums[64];
@@ -992,6 +992,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   const uint32_t incl_b = wave_inclusive_scan(bytes, lane);
   if (lane < K) stream_end[f * 64 + lane] = incl_b;
   if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl_b;
+}
+
+// Two builds of the same body.  The code construction is long chains of serial
+// work per frame, so what counts is how many frames a SIMD holds: four per SIMD
+// (128 registers, a few spills) for batches that need the room, two (all the
+// registers the body wants) while two per SIMD hold the whole batch.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void code_sizes_kernel(
+    uint32_t K, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ counts,
+    FrameCode* __restrict__ code, const FrameCode* __restrict__ given, uint32_t given_step,
+    uint32_t* __restrict__ stream_end, uint32_t* __restrict__ csize) {
+  code_sizes_body(K, hist, counts, code, given, given_step, stream_end, csize);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void code_sizes_kernel_wide(
+    uint32_t K, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ counts,
+    FrameCode* __restrict__ code, const FrameCode* __restrict__ given, uint32_t given_step,
+    uint32_t* __restrict__ stream_end, uint32_t* __restrict__ csize) {
+  code_sizes_body(K, hist, counts, code, given, given_step, stream_end, csize);
 }
 
 // Sum of the per-frame histograms of a batch, 64-bit: total[c] = sum over f of hist[f][c].
@@ -2404,15 +2421,21 @@ int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_byt
   return hipGetLastError();
 }
 
+int device_cus();
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
                       FrameCode* d_code, const FrameCode* d_given, bool shared_code,
                       uint32_t* d_stream_end, uint32_t* d_csize, void* stream,
                       const KernelSpan* span) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  HFZ_LAUNCH(span, code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
-                     (uint32_t)K, d_hist, d_counts, d_code, d_given, shared_code ? 0u : 1u,
-                     d_stream_end, d_csize);
+  if (!d_given && n_frames <= 8 * (uint64_t)device_cus())
+    HFZ_LAUNCH(span, code_sizes_kernel_wide, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                       (uint32_t)K, d_hist, d_counts, d_code, d_given, shared_code ? 0u : 1u,
+                       d_stream_end, d_csize);
+  else
+    HFZ_LAUNCH(span, code_sizes_kernel, dim3((uint32_t)n_frames), dim3(64), 0, as_stream(stream),
+                       (uint32_t)K, d_hist, d_counts, d_code, d_given, shared_code ? 0u : 1u,
+                       d_stream_end, d_csize);
   return hipGetLastError();
 }
 

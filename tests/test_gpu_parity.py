@@ -771,6 +771,18 @@ def test_command_line_tool_round_trip(torch_cuda, tmp_path):
     subprocess.run([tool, "d", "-b", "1", str(packed), str(back)], check=True)
     assert back.read_bytes() == raw
     subprocess.run([tool, "t", str(packed)], check=True)
+    # one host thread and stream per worker: the same files with -g 1, with more GPUs
+    # asked for than the box has (the tool says so and uses what there is), and with
+    # three workers on the one GPU, whose batches have to leave in order
+    for i, extra in enumerate((["-g", "1"], ["-g", "4"], ["-j", "3"], ["-g", "4", "-j", "2"])):
+        packed_g, back_g = tmp_path / ("g%d.hfz" % i), tmp_path / ("g%d.bin" % i)
+        subprocess.run([tool, "c", "-k", "32", "-f", "64", "-b", "1"] + extra + [str(src), str(packed_g)],
+                       check=True, capture_output=True)
+        assert packed_g.read_bytes() == packed.read_bytes(), extra
+        subprocess.run([tool, "d", "-b", "1"] + extra + [str(packed_g), str(back_g)], check=True,
+                       capture_output=True)
+        assert back_g.read_bytes() == raw, extra
+        subprocess.run([tool, "t", "-b", "1"] + extra + [str(packed_g)], check=True, capture_output=True)
     # an empty file and a damaged container
     (tmp_path / "empty").write_bytes(b"")
     subprocess.run([tool, "c", str(tmp_path / "empty"), str(tmp_path / "empty.hfz")], check=True)

@@ -102,3 +102,36 @@ def test_argument_errors():
     assert L.hfz_compress(65, buf, 8, buf, 64, ctypes.byref(got)) == hfz.HFZ_E_ARG
     assert L.hfz_decompress(4, buf, 4, buf, 64, ctypes.byref(got)) == hfz.HFZ_E_CORRUPT
     assert L.hfz_decompressed_size(buf, 8, ctypes.byref(got)) == hfz.HFZ_OK and got.value == 0
+
+
+def test_tool_batch_plan_covers_every_frame_once():
+    # the file tool deals batches of consecutive frames to its workers in turn, the
+    # workers to the GPUs in turn (hfz p prints the plan and needs no GPU): every
+    # frame in exactly one batch, batches in frame order, batch b with worker
+    # b mod W on GPU (worker mod N), never more workers than batches
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(hfz.__file__)), "hfz")
+    if not os.path.exists(tool):
+        pytest.skip("hfz tool not built")
+    for n_frames, per_batch, gpus, per_gpu in ((1, 8, 4, 1), (10, 3, 2, 1), (64, 8, 8, 1), (65, 8, 8, 2),
+                                               (4096, 100, 3, 2), (7, 1, 16, 1), (1000, 1000, 2, 3),
+                                               (20, 4, 1, 3)):
+        out = subprocess.run([tool, "p", str(n_frames), str(per_batch), str(gpus), str(per_gpu)],
+                             capture_output=True, text=True, check=True).stdout.splitlines()
+        head = out[0].split()
+        n_batches, n_gpus, n_workers = int(head[5]), int(head[7]), int(head[9])
+        assert n_batches == -(-n_frames // per_batch)
+        assert n_workers == min(gpus * per_gpu, n_batches) and n_gpus == min(gpus, n_workers)
+        assert len(out) == 1 + n_batches
+        at = 0
+        workers, used_gpus = set(), set()
+        for b, line in enumerate(out[1:]):
+            w = line.split()
+            assert int(w[1]) == b and int(w[3]) == at
+            assert int(w[6]) == b % n_workers and int(w[8]) == int(w[6]) % n_gpus
+            assert 0 < int(w[4]) - int(w[3]) <= per_batch
+            at = int(w[4])
+            workers.add(int(w[6]))
+            used_gpus.add(int(w[8]))
+        assert at == n_frames and workers == set(range(n_workers)) and used_gpus == set(range(n_gpus))
