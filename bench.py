@@ -272,6 +272,10 @@ def main():
                     help="skip the extra workloads measured after the headline one "
                          "(32-stream text-like 1 GiB; the headline batch in 1 MiB frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decoder-table-bits", type=int, default=0,
+                    help="diagnostic: force the decoder's table build (11, 12, -1 = table-free)")
+    ap.add_argument("--decoder-store", type=int, default=0,
+                    help="diagnostic: force the decoder's store mode (1 = every lane its own blocks, 2 = lane pairs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank branches (process group over RCCL, barriers, "
                          "all-reduces) even with one rank, so that they can be run on one GPU")
@@ -304,6 +308,10 @@ def main():
 
     hfz = importlib.import_module("huffman-avx512_amd")
     hfz.lib()  # fails loudly if the HIP library is missing
+    if args.decoder_table_bits:
+        hfz.set_decoder_table_bits(args.decoder_table_bits)
+    if args.decoder_store:
+        hfz.set_decoder_store(args.decoder_store)
 
     K = args.streams
     total = args.total_mib << 20

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "hfz_internal.h"
 
 namespace hfz {
@@ -1450,6 +1452,16 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
 // exact stop (the last symbol may be the first half of a two-symbol entry,
 // Decode1, codec/huffman.cpp:875-878: the second half is clipped).
 constexpr uint32_t kDecInBlk = 64;   // bytes per staged input block
+// Timing experiments only (-DHFZ_EMU_BITS=9|10, never in libhfz.so): the small-table
+// decoder indexes with fewer bits and takes every longer code for one of that
+// many bits, so the output is WRONG; what is measured is the speed a table of
+// that size would allow.  -DHFZ_EMU_SEC adds the price of a second-level table
+// read beside every lookup (a 16-bit read, a compare and a select).
+#ifdef HFZ_EMU_BITS
+constexpr uint32_t kSmallTabBits = HFZ_EMU_BITS;
+#else
+constexpr uint32_t kSmallTabBits = 11;
+#endif
 constexpr uint32_t kDecBlk = 32;     // bytes per stored output block
 constexpr uint32_t kDecRound = 16;   // lookups per round (eight pairs)
 constexpr uint32_t kDecInDw = 32;    // input ring per lane: 128 bytes
@@ -1542,9 +1554,21 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   extern __shared__ uint32_t ringmem_dyn[];
   uint32_t* const ringmem = kParts ? ringmem_dyn : ringmem_one;
   // parts: the length of the first code under every table index stays alive next to the table
-  __shared__ uint8_t l1keep[kParts ? (1u << kDecTabBits) : 4];
-  __shared__ uint32_t cls_keep[kParts ? 16 : 1];
-  __shared__ int wg_bad;  // parts: some thread of the workgroup found its stream corrupt
+  // (the three below only exist with parts: a one-wave workgroup's LDS is its table and rings)
+  uint8_t* l1keep = nullptr;
+  uint32_t* cls_keep = nullptr;
+  int* wg_bad_p = nullptr;  // parts: some thread of the workgroup found its stream corrupt
+  if constexpr (kParts) {
+    __shared__ uint8_t l1keep_s[1u << kDecTabBits];
+    __shared__ uint32_t cls_keep_s[16];
+    __shared__ int wg_bad_s;
+    l1keep = l1keep_s;
+    cls_keep = cls_keep_s;
+    wg_bad_p = &wg_bad_s;
+  }
+#ifdef HFZ_EMU_SEC
+  __shared__ uint16_t emu_sec[kF * (HFZ_EMU_BITS == 9 ? 1024 : 512)];
+#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
   const uint32_t wave = (kWaves == 1 && !kParts) ? 0 : tid >> 6;
@@ -1574,7 +1598,7 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   uint32_t raw_size = 0, hdr_total = 0, end = kSlop;
   uint32_t begin_k = 0;      // parts: where this thread's stream begins in the stream area
   bool multi_symbol = false;  // parts: the code has at least two symbols (every code has a bit)
-  if (kParts && tid == 0) wg_bad = 0;
+  if (kParts && tid == 0) *wg_bad_p = 0;
 
 #pragma unroll
   for (uint32_t pass = 0; pass < kF; ++pass) {
@@ -1738,7 +1762,9 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     // of every length sit in a 13-word list next to the scratch.
     uint32_t* const ptab = tab + (pass << kDecTabBits);
     constexpr uint32_t kTabShift = kTableFree ? 0 : (uint32_t)kMaxCodeLen - kDecTabBits;
+#ifndef HFZ_EMU_BITS
     static_assert(kTabShift <= 1, "sibling entries cover one bit");
+#endif
     // right behind l1tab, still inside the first wave's input ring (the header sits in its output ring)
     uint32_t* const cls = kParts ? cls_keep : ringmem + (kTableFree ? 0 : (1u << kDecTabBits) / 4);
     static_assert(kParts || kTableFree || sizeof(uint32_t) * 64 * kInDw >= (1u << kDecTabBits) + 64,
@@ -1764,13 +1790,19 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
         uint32_t L = 0;
 #pragma unroll
         for (int l = 0; l < kMaxCodeLen; ++l) L += c12 >= fcode[l + 1] ? 1u : 0u;
+#ifdef HFZ_EMU_BITS
+        if (L > kDecTabBits) L = kDecTabBits;
+#endif
         const uint32_t cl = cls[L];
         const uint32_t d = c12 - (cl & 0xffffu);
         // 11-bit table: a 12-bit code shares its entry with its sibling (their
         // number is even: the code is complete), both symbols in the entry; a
         // lone symbol sits in bytes 2 and 3 alike
         const bool sibling = kTabShift && L == (uint32_t)kMaxCodeLen;
-        const uint32_t j = (cl >> 16) + (sibling ? d : d >> ((uint32_t)kMaxCodeLen - L));
+        uint32_t j = (cl >> 16) + (sibling ? d : d >> ((uint32_t)kMaxCodeLen - L));
+#ifdef HFZ_EMU_BITS
+        j &= 255;
+#endif
         const uint32_t s0 = syms[j];
         const uint32_t s1 = sibling ? (uint32_t)syms[j + 1] : (kTabShift ? s0 : 0u);
         ptab[r] = L | (8u << 8) | (s0 << 16) | (s1 << 24);
@@ -1792,6 +1824,10 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
           ptab[r] = (L1 + L2) | (16u << 8) | (ptab[r] & 0xff0000) | ((ptab[rr] & 0xff0000) << 8);
       }
     }
+#ifdef HFZ_EMU_SEC
+    for (uint32_t i = tid; i < (HFZ_EMU_BITS == 9 ? 1024u : 512u); i += n_threads)
+      emu_sec[pass * (HFZ_EMU_BITS == 9 ? 1024u : 512u) + i] = (uint16_t)(syms[i & 255] | (i << 8));
+#endif
     HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
     STAMP(1);  // table
   }
@@ -1906,9 +1942,21 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     HFZ_REFILL();                                                            \
   } while (0)
   // the entry for the code at the bottom of window t_ (bits 2..)
+#ifdef HFZ_EMU_SEC
+  const uint32_t emu_n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((raw_size & 1) + 3));
+  const uint8_t* const emu_secb = (const uint8_t*)(emu_sec + half * (HFZ_EMU_BITS == 9 ? 1024 : 512));
+  constexpr uint32_t kEmuSecMask = ((HFZ_EMU_BITS == 9 ? 1024u : 512u) - 1) << 1;
+#define HFZ_ENTRY(t_)                                                                           \
+  ([&]() {                                                                                      \
+    const uint32_t e1_ = *(const uint32_t*)(tabb + ((t_) & kTabMask));                          \
+    const uint32_t e2_ = *(const uint16_t*)(emu_secb + (((t_) >> emu_n1) & kEmuSecMask));       \
+    return (int32_t)e1_ < 0 ? ((e2_ << 16) | (0x800u + kDecTabBits)) : e1_;                     \
+  }())
+#else
 #define HFZ_ENTRY(t_)                                                                           \
   (kTableFree ? table_free_entry(__builtin_bitreverse32((t_) >> 2) >> 20, fend, tab)            \
               : *(const uint32_t*)(tabb + ((t_) & kTabMask)))
+#endif
   // A round moves the reader down by at most kDecRoundDw dwords and its last
   // refill reads the dword below: a lane can run a round when that many dwords
   // below wnx are staged.
@@ -2089,8 +2137,13 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   // the symbols of an entry, w_ = 8 * their number (in bits 0..4; v_bfe_u32 looks no further).
   // 11-bit table: offset 24 instead of 16 iff the entry counts one symbol (bit 3
   // of w_) and the 12th bit of the code (bit 13 of t_) is set.
+#ifdef HFZ_EMU_BITS
+#define HFZ_EMU_PLAIN (kDecTabBits == kSmallTabBits)
+#else
+#define HFZ_EMU_PLAIN false
+#endif
 #define HFZ_SYMS(e_, t_, w_)                                                                    \
-  ((!kTableFree && kDecTabBits < (uint32_t)kMaxCodeLen)                                         \
+  ((!kTableFree && !HFZ_EMU_PLAIN && kDecTabBits < (uint32_t)kMaxCodeLen)                       \
        ? __builtin_amdgcn_ubfe((e_), ((((t_) >> 10) & (w_)) | 16), (w_))                        \
        : (e_) >> 16)
   // two lookups, their symbols appended to ocur, the finished dword written out,
@@ -2277,9 +2330,9 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   STAMP(7);  // tail
   STAMP_FLUSH(0);
   if (kParts) {  // the verdict of all waves of the frame
-    if (__ballot(stream_bad) != 0 && lane == 0) atomicOr(&wg_bad, 1);
+    if (__ballot(stream_bad) != 0 && lane == 0) atomicOr(wg_bad_p, 1);
     __syncthreads();
-    if (tid == 0 && status) status[f] = wg_bad ? HFZ_E_CORRUPT : HFZ_OK;
+    if (tid == 0 && status) status[f] = *wg_bad_p ? HFZ_E_CORRUPT : HFZ_OK;
     return;
   }
   if (status) {
@@ -2596,9 +2649,17 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   // costs less than the extra resident waves return.
   const int cus = device_cus();
   const int tab_bits = g_decoder_table_bits.load(std::memory_order_relaxed);
+  // Diagnostic only: HFZ_DECODER_LDS_PAD=<bytes> in the environment makes every
+  // one-wave decoder workgroup ask for that much unused LDS on top of its own, so
+  // that fewer of them share a CU (occupancy experiments); read once.
+  static const size_t lds_pad = [] {
+    const char* v = getenv("HFZ_DECODER_LDS_PAD");
+    const long n = v ? atol(v) : 0;
+    return (size_t)(n > 0 && n <= (32 << 10) ? n : 0);
+  }();
 #define HFZ_LAUNCH_DECODE_BLK(BITS, WAVES, F, STORE, BLK)                                         \
   HFZ_LAUNCH(span, (decode_kernel<BITS, WAVES, F, STORE, false, BLK>),                            \
-             dim3((uint32_t)((n_frames + F - 1) / F)), dim3(64 * WAVES), 0, as_stream(stream),    \
+             dim3((uint32_t)((n_frames + F - 1) / F)), dim3(64 * WAVES), lds_pad, as_stream(stream), \
              (uint32_t)K, d_comp, comp_bytes, d_comp_off, d_comp_size, n_frames, d_raw, raw_cap,  \
              frame_bytes, d_status, 0u)
 #define HFZ_LAUNCH_DECODE(BITS, WAVES, F, STORE) HFZ_LAUNCH_DECODE_BLK(BITS, WAVES, F, STORE, 64)
@@ -2661,8 +2722,8 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   }
   if (tab_bits != 12 && pair_frames(K, n_frames)) {
     // two frames per wave, 11-bit tables: 28 KiB of LDS, 5 waves = 10 frames per CU
-    if (small_blocks) HFZ_LAUNCH_DECODE_BLK(11, 1, 2, 0, 32);
-    else HFZ_LAUNCH_DECODE(11, 1, 2, 0);
+    if (small_blocks) HFZ_LAUNCH_DECODE_BLK(kSmallTabBits, 1, 2, 0, 32);
+    else HFZ_LAUNCH_DECODE(kSmallTabBits, 1, 2, 0);
     return hipGetLastError();
   }
   const bool wide = tab_bits ? tab_bits == 12 : n_frames <= (uint64_t)cus * 5;
@@ -2672,13 +2733,13 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   if (wide)
     HFZ_LAUNCH_DECODE(12, 1, 1, 0);
   else if (pair_store && small_blocks)
-    HFZ_LAUNCH_DECODE_BLK(11, 1, 1, 2, 32);
+    HFZ_LAUNCH_DECODE_BLK(kSmallTabBits, 1, 1, 2, 32);
   else if (pair_store)
-    HFZ_LAUNCH_DECODE(11, 1, 1, 2);
+    HFZ_LAUNCH_DECODE(kSmallTabBits, 1, 1, 2);
   else if (small_blocks)
-    HFZ_LAUNCH_DECODE_BLK(11, 1, 1, 1, 32);
+    HFZ_LAUNCH_DECODE_BLK(kSmallTabBits, 1, 1, 1, 32);
   else
-    HFZ_LAUNCH_DECODE(11, 1, 1, 1);
+    HFZ_LAUNCH_DECODE(kSmallTabBits, 1, 1, 1);
 #undef HFZ_LAUNCH_DECODE
 #undef HFZ_LAUNCH_DECODE_BLK
   return hipGetLastError();

@@ -11,7 +11,7 @@ SET2=${PMC_SET2:-"SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ
 for SET in "$SET1" "$SET2"; do
   i=$((i+1))
   timeout -s KILL 180 rocprofv3 --pmc $SET --output-format csv -d "$OUT/p$i" -- \
-      python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined "$@" > "$OUT/p$i.log" 2>&1 || { tail -5 "$OUT/p$i.log"; exit 2; }
+      python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-side "$@" > "$OUT/p$i.log" 2>&1 || { tail -5 "$OUT/p$i.log"; exit 2; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, re, collections
