@@ -1837,7 +1837,9 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     return;
   }
   const uint8_t* const tabb = (const uint8_t*)(tab + (half << kDecTabBits));
-  constexpr uint32_t kTabMask = kTableFree ? 0 : ((1u << kDecTabBits) - 1) << 2;
+  // the lookup mask lives in a scalar register (K < 2^30: the OR adds nothing, but the
+  // compiler cannot fold it): an AND with a 32-bit literal is an 8-byte instruction
+  const uint32_t kTabMask = (kTableFree ? 0 : ((1u << kDecTabBits) - 1) << 2) | (K >> 30);
 
   // Input side: offsets are relative to cbase, a 64-byte aligned address 256
   // bytes below the frame, so that the block arithmetic below (up to three
@@ -1907,13 +1909,16 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   const uint32_t ra_area = (31u - (area_off >> 2)) << 8;
   const uint8_t* const icol = (const uint8_t*)irow;
   constexpr uint32_t kInRowMask = (kInDw - 1) << 8;
+  // acc_ += x_ << 3 as ONE instruction (left to itself the compiler keeps a second
+  // running sum and rebuilds acc_ from it: two instructions per step)
+#define HFZ_LSHL3_ADD(acc_, x_) asm("v_lshl_add_u32 %0, %1, 3, %0" : "+v"(acc_) : "v"(x_))
   // after a pair: wlo used up -> whi:wlo <- wnx:whi, and the next wnx is read
 #define HFZ_REFILL()                                                         \
   do {                                                                       \
     const uint32_t z_ = sacc & 32;                                           \
     wlo = z_ ? whi : wlo;                                                    \
     whi = z_ ? wnx : whi;                                                    \
-    ra = (z_ << 3) + ra; /* v_lshl_add_u32 */                                \
+    HFZ_LSHL3_ADD(ra, z_);                                                   \
     sacc &= 31;                                                              \
     wnx = *(const uint32_t*)(icol + (ra & kInRowMask));                      \
   } while (0)
@@ -2166,7 +2171,7 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     *(uint32_t*)(ocol + (wa & kOutRowMask)) = lo_;                           \
     const uint32_t f_ = sh & 32;                                             \
     ocur = (uint32_t)(((sp_ & 0xffffffff00000000ull) | lo_) >> f_);          \
-    wa += f_ << 3;                                                           \
+    HFZ_LSHL3_ADD(wa, f_);                                                   \
     sh &= 31;                                                                \
     HFZ_REFILL();                                                            \
   } while (0)
@@ -2318,6 +2323,7 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     }
   }
 #undef HFZ_REFILL
+#undef HFZ_LSHL3_ADD
 #undef HFZ_ENTRY
 #undef HFZ_SYMS
 #undef HFZ_PAIR
