@@ -597,15 +597,7 @@ int hfz_generate_dev(const uint32_t* d_cdf, uint64_t seed, uint64_t first_index,
 // ---- host-buffer single-frame entry points --------------------------------
 
 namespace {
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-};
-
-// Buffers of the host-buffer entry points (hfz_compress / hfz_decompress): one
+// Buffers of the host-buffer entry points (hfz_compress / hfz_decompress / hfz_histogram): one
 // device allocation, one pinned host allocation and one stream, kept between
 // calls so that a call costs two copies, the kernels and ONE synchronisation
 // instead of four allocations and three blocking copies.  A call takes an
@@ -695,13 +687,27 @@ size_t up256(size_t n) { return (n + 255) & ~size_t(255); }
 int hfz_histogram(const void* src, size_t n, uint32_t hist[256]) {
   if (!hist || (n && !src)) return HFZ_E_ARG;
   if (!have_device()) return HFZ_E_NO_DEVICE;
-  DevBuf d_src, d_hist;
-  HFZ_HIP(d_src.alloc(n));
-  HFZ_HIP(d_hist.alloc(256 * sizeof(uint32_t)));
-  if (n) HFZ_HIP(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
-  int rc = hfz_histogram_dev(d_src.p, n, (uint32_t*)d_hist.p, nullptr);
-  if (rc != HFZ_OK) return rc;
-  HFZ_HIP(hipMemcpy(hist, d_hist.p, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  // device: 256 counters | input, from the pooled arena (no allocation once it is warm)
+  constexpr size_t kHistBytes = 256 * sizeof(uint32_t);
+  constexpr size_t kStaged = size_t(4) << 20;  // larger inputs are copied from the caller's memory directly
+  const bool staged = n <= kStaged;
+  ArenaLease lease;
+  if (!lease.ok) return HFZ_E_HIP;
+  Arena& ar = lease.a;
+  HFZ_HIP(ar.reserve(kHistBytes + n, std::max(staged ? n : size_t(0), kHistBytes)));
+  hipStream_t st = ar.stream;
+  if (n) {
+    if (staged) std::memcpy(ar.pin, src, n);
+    HFZ_HIP(hipMemcpyAsync(ar.dev + kHistBytes, staged ? (const void*)ar.pin : src, n, hipMemcpyHostToDevice, st));
+  }
+  int rc = hfz_histogram_dev(ar.dev + kHistBytes, n, (uint32_t*)ar.dev, st);
+  if (rc != HFZ_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  HFZ_HIP(hipMemcpyAsync(ar.pin, ar.dev, kHistBytes, hipMemcpyDeviceToHost, st));
+  HFZ_HIP(hipStreamSynchronize(st));
+  std::memcpy(hist, ar.pin, kHistBytes);
   return HFZ_OK;
 }
 

@@ -19,7 +19,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(\w+_kernel)(?:<[^>]*>)?\(", r["Kernel_Name"])
+        m = re.search(r"(\w+_kernel(?:_wide)?)(?:<[^>]*>)?\(", r["Kernel_Name"])
         if m and "hfz::" in r["Kernel_Name"]:
             acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel)(?:<[^>]*>)?\(", name)
+    m = re.search(r"(\w+_kernel(?:_wide)?)(?:<[^>]*>)?\(", name)
     return m.group(1) if m else None
 
 
