@@ -2661,7 +2661,7 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   static const size_t lds_pad = [] {
     const char* v = getenv("HFZ_DECODER_LDS_PAD");
     const long n = v ? atol(v) : 0;
-    return (size_t)(n > 0 && n <= (32 << 10) ? n : 0);
+    return (size_t)(n > 0 && n <= (140 << 10) ? n : 0);
   }();
 #define HFZ_LAUNCH_DECODE_BLK(BITS, WAVES, F, STORE, BLK)                                         \
   HFZ_LAUNCH(span, (decode_kernel<BITS, WAVES, F, STORE, false, BLK>),                            \
