@@ -268,8 +268,10 @@ size_t hfz_batch_frames(size_t total, size_t frame_bytes) {
 }
 
 size_t hfz_workspace_bytes(int K, size_t n_frames) {
-  (void)K;
-  return workspace_layout(n_frames).total;
+  // a batch of few frames is counted in pieces (more workgroups, and the encoder's
+  // parts learn their first bits from it): room for the most pieces it can take
+  const uint32_t split = (K >= 1 && K <= HFZ_MAX_STREAMS) ? max_split_log2(K, n_frames) : 0;
+  return split ? split_layout(n_frames, split).total : workspace_layout(n_frames).total;
 }
 
 int hfz_histogram_batch_dev(const void* d_raw, size_t total, size_t frame_bytes, uint32_t* d_hist,
@@ -331,17 +333,37 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
   const FrameCode* enc_code = shared ? d_shared : d_code;
 
   HFZ_HIP(g_timing.take(g_timing.enc, g_timing.enc_calls, g_timing.enc_seen, kEncEvents, nf));
+  // how many threads the encoder will put on a stream: asked once, here, so that
+  // counting and encoding agree whatever happens to the knobs in between
+  const uint32_t enc_parts = encoder_parts_plan(K, nf, frame_bytes);
+  const uint32_t* d_part_first = nullptr;
   if (count_kernel_fits(K, frame_bytes)) {
     // one pass over the input for the per-stream counts (hist_ms), then code and
     // stream sizes from those (table_ms); sizes_ms reads 0.  With a shared code
     // the counting kernel turns the counts into sizes itself.
-    uint32_t* d_counts = (uint32_t*)(ws + w.counts);
-    HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, shared ? d_shared : nullptr, shared,
-                         shared ? nullptr : d_counts, shared ? nullptr : d_hist, d_send, d_csize,
-                         stream, g_timing.enc_span(0)));
-    if (!shared)
-      HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, nullptr, false, d_send, d_csize,
-                                stream, g_timing.enc_span(1)));
+    const bool split = !shared && enc_parts >= 1 && enc_parts <= kMaxSplitLog2 &&
+                       ws_bytes >= split_layout(nf, enc_parts).total;
+    if (split) {
+      // few frames: every stream is counted in the encoder's parts, one workgroup per
+      // part, and the parts' first bits come out of the size computation
+      const SplitLayout sl = split_layout(nf, enc_parts);
+      uint32_t* d_pf = (uint32_t*)(ws + sl.part_first);
+      HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, nullptr, false,
+                           (uint32_t*)(ws + sl.counts_u), (uint32_t*)(ws + sl.hist_u), d_send,
+                           d_csize, stream, g_timing.enc_span(0), enc_parts));
+      HFZ_HIP(launch_code_sizes_split(K, (const uint32_t*)(ws + sl.hist_u),
+                                      (const uint32_t*)(ws + sl.counts_u), nf, enc_parts, d_code,
+                                      d_pf, d_send, d_csize, stream, g_timing.enc_span(1)));
+      d_part_first = d_pf;
+    } else {
+      uint32_t* d_counts = (uint32_t*)(ws + w.counts);
+      HFZ_HIP(launch_count(K, raw, total, frame_bytes, nf, shared ? d_shared : nullptr, shared,
+                           shared ? nullptr : d_counts, shared ? nullptr : d_hist, d_send, d_csize,
+                           stream, g_timing.enc_span(0)));
+      if (!shared)
+        HFZ_HIP(launch_code_sizes(K, d_hist, d_counts, nf, d_code, nullptr, false, d_send, d_csize,
+                                  stream, g_timing.enc_span(1)));
+    }
   } else {
     // the code is built inside the sizes kernel (table_ms reads 0)
     if (!shared)
@@ -354,7 +376,8 @@ int compress_batch(int K, const void* d_raw, size_t total, size_t frame_bytes, v
   HFZ_HIP(launch_frame_offsets(d_csize, nf, comp_stride, comp_cap, d_comp_off, d_comp_size,
                                d_status, stream, g_timing.enc_span(3)));
   HFZ_HIP(launch_encode(K, raw, total, frame_bytes, nf, enc_code, shared, d_send, d_comp_off,
-                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream, g_timing.enc_span(4)));
+                        d_comp_size, (uint8_t*)d_comp, comp_cap, stream, g_timing.enc_span(4),
+                        (int)enc_parts, d_part_first));
   g_timing.cur = nullptr;
   return HFZ_OK;
 }

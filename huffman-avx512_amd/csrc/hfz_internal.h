@@ -38,6 +38,17 @@ struct WorkspaceLayout {
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// A batch of few frames is counted in 2^log2 pieces per stream (count_kernel's
+// split): the units' histograms and counters and the first bit of every piece lie
+// behind the ordinary workspace of the batch.
+constexpr uint32_t kMaxSplitLog2 = 3;
+struct SplitLayout {
+  size_t hist_u;      // u32 [n << log2][256]
+  size_t counts_u;    // u32 [n << log2][256][32]
+  size_t part_first;  // u32 [n][64][8]
+  size_t total;
+};
+
 inline WorkspaceLayout workspace_layout(size_t n) {
   WorkspaceLayout w;
   size_t off = 0;
@@ -51,6 +62,20 @@ inline WorkspaceLayout workspace_layout(size_t n) {
   off = align256(off + n * sizeof(uint32_t));
   w.counts = off;
   off = align256(off + n * 256 * 32 * sizeof(uint32_t));
+  w.total = off;
+  return w;
+}
+
+inline SplitLayout split_layout(size_t n, uint32_t log2) {
+  SplitLayout w;
+  size_t off = workspace_layout(n).total;
+  const size_t units = n << log2;
+  w.hist_u = off;
+  off = align256(off + units * 256 * sizeof(uint32_t));
+  w.counts_u = off;
+  off = align256(off + units * 256 * 32 * sizeof(uint32_t));
+  w.part_first = off;
+  off = align256(off + n * 64 * 8 * sizeof(uint32_t));
   w.total = off;
   return w;
 }
@@ -113,10 +138,21 @@ inline bool count_kernel_fits(int K, uint64_t frame_bytes) {
 }
 // d_counts_out != nullptr: writes the per-stream counters and d_hist_out for
 // launch_code_sizes; == nullptr: d_code is given and the sizes are final.
+// split_log2 > 0: every stream is counted in 2^split_log2 pieces, one workgroup and one set of
+// counters and histogram per piece (d_counts_out / d_hist_out hold n_frames << split_log2 units).
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                  uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
-                 uint32_t* d_csize, void* stream, const KernelSpan* span = nullptr);
+                 uint32_t* d_csize, void* stream, const KernelSpan* span = nullptr,
+                 uint32_t split_log2 = 0);
+// code and stream sizes of a batch counted in pieces; also the first bit of every piece
+int launch_code_sizes_split(int K, const uint32_t* d_hist_u, const uint32_t* d_counts_u,
+                            uint64_t n_frames, uint32_t split_log2, FrameCode* d_code,
+                            uint32_t* d_part_first, uint32_t* d_stream_end, uint32_t* d_csize,
+                            void* stream, const KernelSpan* span = nullptr);
+// threads per stream (log2) the encoder will use on a batch; pieces hfz_workspace_bytes provides for
+uint32_t encoder_parts_plan(int K, uint64_t n_frames, uint64_t frame_bytes);
+uint32_t max_split_log2(int K, uint64_t n_frames);
 // d_given == nullptr: builds d_code[f] from d_hist[f]; otherwise no code is built and the
 // sizes are those under d_given (per frame, or one for all with shared_code).
 int launch_code_sizes(int K, const uint32_t* d_hist, const uint32_t* d_counts, uint64_t n_frames,
@@ -132,7 +168,8 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream,
-                  const KernelSpan* span = nullptr);
+                  const KernelSpan* span = nullptr, int plan_log2_parts = -1,
+                  const uint32_t* d_part_first = nullptr);
 int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint64_t n_frames, bool shared_code, uint8_t* d_raw,
                   uint64_t raw_cap, uint64_t frame_bytes, int32_t* d_status, void* stream,

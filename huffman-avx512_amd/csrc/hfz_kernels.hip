@@ -791,15 +791,23 @@ __device__ __forceinline__ void count_range(const uint8_t* __restrict__ ibase, u
 // counts_out == null: code[f * code_step] is given (code_step = 0: one code for
 // every frame) and the stream sizes
 // are computed right here.  hist_out may be null then.
+// split_log2 > 0 (counts_out only): 2^split_log2 workgroups per frame; workgroup sp
+// of frame f counts piece sp of every stream, the pieces cut like SliceSizes cuts
+// a frame (the cut of the several-threads-per-stream encoder), and writes counters
+// and histogram of unit f * 2^split_log2 + sp.  Few-frame batches get more
+// workgroups that way, and the encoder learns where every piece's bits begin
+// without adding up code lengths in a pass of its own.
 __global__ __launch_bounds__(kCntThreads) void count_kernel(
     uint32_t K, const uint8_t* __restrict__ raw, uint64_t total, uint64_t frame_bytes,
     const FrameCode* __restrict__ code, uint32_t code_step, uint32_t* __restrict__ counts_out,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ stream_end,
-    uint32_t* __restrict__ csize) {
+    uint32_t* __restrict__ csize, uint32_t split_log2) {
   __shared__ __align__(16) uint32_t cnt[256 * 32];
   __shared__ uint32_t lens4[64];  // code length of symbol s in byte s & 3 of word s >> 2
   __shared__ uint32_t part_bits[kCntThreads / 64][64];
-  const uint64_t f = blockIdx.x;
+  const uint64_t unit = blockIdx.x;  // where counters and histogram go
+  const uint64_t f = unit >> split_log2;
+  const uint32_t split_piece = (uint32_t)(unit & ((1u << split_log2) - 1));
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < 256 * 32; i += kCntThreads) cnt[i] = 0;
   __syncthreads();
@@ -811,7 +819,12 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
   {
     const uint32_t stream = tid % K, part = tid / K;
     if (part < parts) {
-      const Slice s = slice_of(n, K, stream);
+      Slice s = slice_of(n, K, stream);
+      if (split_log2) {  // this workgroup's piece of the stream
+        const Slice ps = slice_of(s.size, 1u << split_log2, split_piece);
+        s.begin += ps.begin;
+        s.size = ps.size;
+      }
       const uint32_t chunk = ((s.size + parts - 1) / parts + kCntBlk - 1) & ~(kCntBlk - 1);
       const uint32_t rel_lo = part * chunk < s.size ? part * chunk : s.size;
       const uint32_t rel_hi = rel_lo + chunk < s.size ? rel_lo + chunk : s.size;
@@ -833,7 +846,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
     const uint32_t w = cnt[tid * 32 + ((c + tid) & 31)];
     sum += packed ? (w & 0xffff) + (w >> 16) : w;
   }
-  if (hist_out) hist_out[f * 256 + tid] = sum;
+  if (hist_out) hist_out[unit * 256 + tid] = sum;
   if (counts_out) {
     // Only the rows of byte values that occur go to memory, packed in ascending
     // order of the value (a fifth of the rows on the reference's biased source);
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(kCntThreads) void count_kernel(
     uint8_t* const row_of = (uint8_t*)lens4;  // 256 bytes
     if (occurs) row_of[at] = (uint8_t)tid;
     __syncthreads();
-    uint4* dst = (uint4*)(counts_out + f * (256 * 32));
+    uint4* dst = (uint4*)(counts_out + unit * (256 * 32));
     const uint4* src = (const uint4*)cnt;
     for (uint32_t i = tid; i < 8 * n_rows; i += kCntThreads) dst[i] = src[8 * (uint32_t)row_of[i >> 3] + (i & 7)];
     return;
@@ -1013,6 +1026,118 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   code_sizes_body(K, hist, counts, code, given, given_step, stream_end, csize);
 }
 
+// The same for a batch counted in pieces (count_kernel with split_log2 > 0): the
+// frame's histogram is the sum of its units', the code is built from that, and
+// the coded bits of piece sp of stream k come from unit f * P + sp's counters.
+// Their running sums are the first bit of every piece, which go to
+// part_first[(f * 64 + k) * 8 + sp] for the several-threads-per-stream encoder
+// (P = 2^split_log2 <= 8 pieces, the encoder's parts), and the last one is the
+// stream's size.  One wave per piece: all of them fetch their unit's histogram
+// and the first of its counters, wave 0 builds the code while those loads are in
+// flight, then every wave weighs its unit's counters and wave 0 adds up.
+constexpr uint32_t kMaxSplit = 1u << kMaxSplitLog2;
+__global__ __launch_bounds__(64 * kMaxSplit) void code_sizes_split_kernel(
+    uint32_t K, const uint32_t* __restrict__ hist_u, const uint32_t* __restrict__ counts_u,
+    FrameCode* __restrict__ code, uint32_t split_log2, uint32_t* __restrict__ part_first,
+    uint32_t* __restrict__ stream_end, uint32_t* __restrict__ csize) {
+  __shared__ uint32_t lens[256];
+  __shared__ __align__(16) uint32_t hu[kMaxSplit][256];  // the units' histograms
+  __shared__ __align__(16) uint32_t hsum[256];           // the frame's
+  __shared__ uint32_t row_len[kMaxSplit][256];  // code length of the byte value of packed row j of a unit
+  __shared__ uint32_t sums[kMaxSplit][64];      // coded bits of (piece, stream)
+  const uint64_t f = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t P = 1u << split_log2;  // = waves of this workgroup
+  const uint64_t u = f * P + wave;
+  const uint32_t* rows = counts_u + u * (256 * 32) + lane;  // word (packed row l/32, column l%32)
+  // the counters do not depend on the code: start fetching them now (row pairs past
+  // the last packed one hold stale data and are skipped below)
+  constexpr uint32_t kAhead = 8;
+  uint32_t nxt[kAhead];
+#pragma unroll
+  for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * i];
+  // which byte values occur in this unit: lane l looks at values 4l .. 4l+3
+  const uint4 h4 = *(const uint4*)(hist_u + u * 256 + 4 * lane);
+  *(uint4*)(&hu[wave][4 * lane]) = h4;
+  sums[wave][lane] = 0;
+  __syncthreads();
+  if (wave == 0) {
+    uint4 a = make_uint4(0, 0, 0, 0);
+    for (uint32_t sp = 0; sp < P; ++sp) {
+      const uint4 h = *(const uint4*)(&hu[sp][4 * lane]);
+      a.x += h.x;
+      a.y += h.y;
+      a.z += h.z;
+      a.w += h.w;
+    }
+    *(uint4*)(hsum + 4 * lane) = a;
+    wave_sync();
+    const uint16_t* encs = build_code(hsum, code + f, lane);
+    for (uint32_t i = lane; i < 256; i += 64) lens[i] = encs[i] & 15;
+  }
+  __syncthreads();
+  const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
+  uint32_t nz = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nz += hv[j] != 0;
+  const uint32_t incl = wave_inclusive_scan(nz, lane);
+  const uint32_t n_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63, 64));
+  {
+    uint32_t at = incl - nz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (hv[j] != 0) row_len[wave][at++] = lens[4 * lane + j];
+  }
+  wave_sync();
+  const bool packed = K > 32;
+  const uint32_t reps = packed ? 1 : 32 / K;
+  const uint32_t col = lane & 31, par = lane >> 5;
+  uint32_t acc_lo = 0, acc_hi = 0;
+  const uint32_t n_groups = ((n_rows + 1) / 2 + kAhead - 1) / kAhead;  // kAhead row pairs each
+  for (uint32_t g = 0; g < n_groups; ++g) {
+    uint32_t cur[kAhead];
+#pragma unroll
+    for (uint32_t i = 0; i < kAhead; ++i) cur[i] = nxt[i];
+    if (g + 1 < n_groups) {
+#pragma unroll
+      for (uint32_t i = 0; i < kAhead; ++i) nxt[i] = rows[64 * (kAhead * (g + 1) + i)];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kAhead; ++i) {
+      const uint32_t r = 2 * (kAhead * g + i) + par;
+      const uint32_t len = r < n_rows ? row_len[wave][r] : 0;
+      const uint32_t c = r < n_rows ? cur[i] : 0;
+      if (packed) {
+        acc_lo += (c & 0xffff) * len;
+        acc_hi += (c >> 16) * len;
+      } else {
+        acc_lo += c * len;
+      }
+    }
+  }
+  if (packed) {
+    atomicAdd(&sums[wave][col], acc_lo);
+    atomicAdd(&sums[wave][col + 32], acc_hi);
+  } else if (col < K * reps) {
+    atomicAdd(&sums[wave][col % K], acc_lo);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const uint32_t hdr_len = code[f].hdr_len;  // written by lane 0 of this wave inside build_code
+  uint32_t run = 0;  // lane k: bits of stream k before the piece at hand
+  if (lane < K) {
+    for (uint32_t sp = 0; sp < P; ++sp) {
+      part_first[(f * 64 + lane) * 8 + sp] = run;
+      run += sums[sp][lane];
+    }
+  }
+  uint32_t bytes = 0;
+  if (lane < K) bytes = (run + 7) / 8 + kSlop;
+  const uint32_t incl_b = wave_inclusive_scan(bytes, lane);
+  if (lane < K) stream_end[f * 64 + lane] = incl_b;
+  if (lane == K - 1) csize[f] = 4 + hdr_len + 4 * (K - 1) + incl_b;
+}
+
 // Sum of the per-frame histograms of a batch, 64-bit: total[c] = sum over f of hist[f][c].
 __global__ __launch_bounds__(256) void hist_total_kernel(const uint32_t* __restrict__ hist,
                                                          uint64_t n_frames,
@@ -1116,7 +1241,8 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
     uint64_t n_frames, const FrameCode* __restrict__ code, uint32_t code_step,
     const uint32_t* __restrict__ stream_end,
     const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_size,
-    uint8_t* __restrict__ comp, uint64_t cap, uint32_t log2_parts) {
+    uint8_t* __restrict__ comp, uint64_t cap, uint32_t log2_parts,
+    const uint32_t* __restrict__ part_first) {
   static_assert(kF == 1 || kF == 2, "one or two frames per wave");
   static_assert(!kParts || kF == 1, "parts: one frame per workgroup");
   static_assert(kEncOutBlk == 32 || kEncOutBlk == 64, "the ring holds four or two blocks");
@@ -1189,7 +1315,7 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
     // sum).  The part is read in groups of four aligned 16-byte blocks with the
     // next group in flight; addresses past the part are clamped to its last block.
     uint32_t bits = 0;
-    {
+    if (!part_first) {
       const uint32_t first16 = in_lo & ~15u;
       const uint32_t n16 = ps.size ? ((in_hi + 15) >> 4) - (in_lo >> 4) : 0;
       const uint32_t last16 = n16 ? first16 + 16 * (n16 - 1) : first16;
@@ -1233,13 +1359,23 @@ __global__ __launch_bounds__(kParts ? 512 : 64) void encode_kernel(
       }
 #undef HFZ_LOAD4
     }
-    // first bit of every part: prefix sum over the threads of the stream
+    // first bit of every part: prefix sum over the threads of the stream, or, for a
+    // batch that was counted piece by piece (count_kernel with split_log2 =
+    // log2_parts), read from what code_sizes_split_kernel left: no pass over the
+    // input was needed then
     uint32_t incl = bits;
-    for (uint32_t d = 1; d < n_parts; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, (int)n_parts);
-      if (part >= d) incl += o;
+    uint32_t first_bit;
+    if (part_first) {
+      const uint32_t* pf = part_first + (f * 64 + k) * 8;
+      first_bit = pf[part];
+      incl = part + 1 < n_parts ? pf[part + 1] : first_bit;  // the last part's end is the stream's
+    } else {
+      for (uint32_t d = 1; d < n_parts; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, (int)n_parts);
+        if (part >= d) incl += o;
+      }
+      first_bit = incl - bits;
     }
-    const uint32_t first_bit = incl - bits;
     const uint32_t stream_hi = r_hi;
     r_hi = stream_hi - (first_bit >> 3);
     if (part != n_parts - 1) r_lo = stream_hi - (incl >> 3);
@@ -2469,14 +2605,28 @@ int launch_stream_sizes(int K, const uint8_t* d_raw, uint64_t total, uint64_t fr
 int launch_count(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                  uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                  uint32_t* d_counts_out, uint32_t* d_hist_out, uint32_t* d_stream_end,
-                 uint32_t* d_csize, void* stream, const KernelSpan* span) {
+                 uint32_t* d_csize, void* stream, const KernelSpan* span, uint32_t split_log2) {
   if (n_frames == 0) return hipSuccess;
-  if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+  if (n_frames > 0x7fffffffull || (n_frames << split_log2) > 0x7fffffffull) return hipErrorInvalidValue;
   if (!count_kernel_fits(K, frame_bytes)) return hipErrorInvalidValue;
   if (d_counts_out ? d_hist_out == nullptr : d_code == nullptr) return hipErrorInvalidValue;
-  HFZ_LAUNCH(span, count_kernel, dim3((uint32_t)n_frames), dim3(kCntThreads), 0,
+  if (split_log2 && !d_counts_out) return hipErrorInvalidValue;  // pieces only on the way to code_sizes_split
+  HFZ_LAUNCH(span, count_kernel, dim3((uint32_t)(n_frames << split_log2)), dim3(kCntThreads), 0,
                      as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, d_code,
-                     shared_code ? 0u : 1u, d_counts_out, d_hist_out, d_stream_end, d_csize);
+                     shared_code ? 0u : 1u, d_counts_out, d_hist_out, d_stream_end, d_csize,
+                     split_log2);
+  return hipGetLastError();
+}
+
+int launch_code_sizes_split(int K, const uint32_t* d_hist_u, const uint32_t* d_counts_u,
+                            uint64_t n_frames, uint32_t split_log2, FrameCode* d_code,
+                            uint32_t* d_part_first, uint32_t* d_stream_end, uint32_t* d_csize,
+                            void* stream, const KernelSpan* span) {
+  if (n_frames == 0) return hipSuccess;
+  if (n_frames > 0x7fffffffull || split_log2 == 0 || split_log2 > kMaxSplitLog2) return hipErrorInvalidValue;
+  HFZ_LAUNCH(span, code_sizes_split_kernel, dim3((uint32_t)n_frames), dim3(64u << split_log2), 0, as_stream(stream),
+                     (uint32_t)K, d_hist_u, d_counts_u, d_code, split_log2, d_part_first,
+                     d_stream_end, d_csize);
   return hipGetLastError();
 }
 
@@ -2590,29 +2740,55 @@ uint32_t decoder_log2_parts(int K, uint64_t n_frames, uint64_t frame_bytes) {
   return l >= 2 ? l : 0;
 }
 
+// Threads per stream (as a power of two) that the encoder will use on this batch:
+// none with two frames per wave, else encoder_log2_parts() cut down to what the
+// device's LDS holds (the rings of a parts launch: 8 KiB per wave of dynamic LDS,
+// beyond the 64 KiB a launch may ask for by default when all eight waves are used,
+// next to 2 KiB of static LDS).
+uint32_t encoder_parts_plan(int K, uint64_t n_frames, uint64_t frame_bytes) {
+  if (pair_frames(K, n_frames)) return 0;
+  uint32_t log2_parts = encoder_log2_parts(K, n_frames, frame_bytes);
+  for (;; --log2_parts) {
+    const uint32_t threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
+    const size_t ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
+    if (log2_parts == 0 || ring_bytes + 2048 <= device_lds_per_block()) break;
+  }
+  return log2_parts;
+}
+
+// The most pieces per stream (as a power of two) that a batch of n_frames frames
+// can be counted in, whatever its frame size: what hfz_workspace_bytes provides for.
+uint32_t max_split_log2(int K, uint64_t n_frames) {
+  if (K > 32 ? false : g_frames_per_wave.load(std::memory_order_relaxed) == 2) return 0;
+  uint32_t max_log2 = 0;
+  while (max_log2 < kMaxSplitLog2 && ((uint64_t)K << (max_log2 + 1)) <= 512) ++max_log2;
+  const uint64_t want_threads = 4ull * 64 * (uint64_t)device_cus();
+  uint32_t l = 0;
+  while (l < max_log2 && (n_frames * (uint64_t)K << l) < want_threads) ++l;
+  return l;
+}
+
+// plan_log2_parts: what encoder_parts_plan() said when the batch was counted (the
+// caller asked once, so that counting and encoding agree); d_part_first: first bit
+// of every part from code_sizes_split_kernel, or null (the parts add up their
+// code lengths themselves).
 int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_bytes,
                   uint64_t n_frames, const FrameCode* d_code, bool shared_code,
                   const uint32_t* d_stream_end, const uint64_t* d_comp_off,
                   const uint32_t* d_comp_size, uint8_t* d_comp, uint64_t comp_cap, void* stream,
-                  const KernelSpan* span) {
+                  const KernelSpan* span, int plan_log2_parts, const uint32_t* d_part_first) {
   if (n_frames == 0) return hipSuccess;
   if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-  const bool pair = pair_frames(K, n_frames);
   const int enc_blk = g_encoder_block.load(std::memory_order_relaxed);
   const bool wide = enc_blk ? enc_blk == 64
                             : n_frames > 4 * (uint64_t)device_cus();  // > one wave per SIMD
-  uint32_t log2_parts = pair ? 0 : encoder_log2_parts(K, n_frames, frame_bytes);
+  const uint32_t log2_parts = plan_log2_parts >= 0 ? (uint32_t)plan_log2_parts
+                                                   : encoder_parts_plan(K, n_frames, frame_bytes);
+  const bool pair = log2_parts == 0 && pair_frames(K, n_frames);
+  if (log2_parts == 0) d_part_first = nullptr;
   const dim3 grid((uint32_t)(pair ? (n_frames + 1) / 2 : n_frames));
-  // the rings of a parts launch: 8 KiB per wave of dynamic LDS (beyond the 64 KiB a
-  // launch may ask for by default when all eight waves are used), next to 2 KiB of
-  // static LDS; fewer parts where the device gives a workgroup less than that
-  uint32_t threads;
-  size_t ring_bytes;
-  for (;; --log2_parts) {
-    threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
-    ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
-    if (log2_parts == 0 || ring_bytes + 2048 <= device_lds_per_block()) break;
-  }
+  const uint32_t threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
+  const size_t ring_bytes = log2_parts ? (threads / 64) * 64 * kEncRingDw * sizeof(uint32_t) : 0;
 #define HFZ_LAUNCH_ENCODE(F, B, P)                                                               \
   do {                                                                                           \
     if (ring_bytes > (48u << 10)) {                                                              \
@@ -2624,7 +2800,7 @@ int launch_encode(int K, const uint8_t* d_raw, uint64_t total, uint64_t frame_by
     HFZ_LAUNCH(span, (encode_kernel<F, B, P>), grid, dim3(threads), ring_bytes,                  \
                        as_stream(stream), (uint32_t)K, d_raw, total, frame_bytes, n_frames,      \
                        d_code, shared_code ? 0u : 1u, d_stream_end, d_comp_off, d_comp_size,     \
-                       d_comp, comp_cap, log2_parts);                                            \
+                       d_comp, comp_cap, log2_parts, d_part_first);                              \
   } while (0)
   if (log2_parts && wide) HFZ_LAUNCH_ENCODE(1, 64, true);
   else if (log2_parts) HFZ_LAUNCH_ENCODE(1, 32, true);

@@ -133,7 +133,12 @@ int hfz_build_codes_dev(const uint32_t* d_hist, size_t n, hfz_frame_code* d_code
  * offsets, and 32 KiB for the per-stream counters of the byte values that occur;
  * large slices and the shared-code encoder with a given code do not touch the
  * counters, but the size is checked all the same).  For small frames it exceeds
- * the raw data; allocate it once and reuse it.
+ * the raw data; allocate it once and reuse it.  A batch with too few frames to
+ * fill the chip one wavefront per frame (n_frames * K below about 65 000) gets
+ * room on top for counting every stream in up to eight pieces (33 KiB per piece
+ * and frame: the several-threads-per-stream encoder then knows where each
+ * thread's bits begin without a pass of its own over the input); a caller that
+ * passes only the 35 KiB per frame gets the same bytes from the slower path.
  */
 size_t hfz_batch_frames(size_t total, size_t frame_bytes);
 size_t hfz_workspace_bytes(int K, size_t n_frames);

@@ -141,7 +141,7 @@ def test_encoder_block_sizes(torch_cuda):
         hfz.set_encoder_block(0)
 
 
-@pytest.mark.parametrize("parts", [2, 4, 16, 64])
+@pytest.mark.parametrize("parts", [2, 4, 8, 16, 64])
 def test_encoder_parts_per_stream(torch_cuda, parts):
     # several threads per stream (chosen automatically for batches of few frames,
     # which includes every single-frame call above): force part counts over every
