@@ -1694,13 +1694,19 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
   uint8_t* l1keep = nullptr;
   uint32_t* cls_keep = nullptr;
   int* wg_bad_p = nullptr;  // parts: some thread of the workgroup found its stream corrupt
+  // parts: for every 12-bit (reversed) window the whole codes that lie in it: their bits in
+  // byte 0, their number in byte 1.  Counting the symbols of a piece needs no symbols, so it
+  // can take up to twelve codes per lookup where the decoding table gives two.
+  uint16_t* cntab = nullptr;
   if constexpr (kParts) {
     __shared__ uint8_t l1keep_s[1u << kDecTabBits];
     __shared__ uint32_t cls_keep_s[16];
     __shared__ int wg_bad_s;
+    __shared__ uint16_t cntab_s[1u << kMaxCodeLen];
     l1keep = l1keep_s;
     cls_keep = cls_keep_s;
     wg_bad_p = &wg_bad_s;
+    cntab = cntab_s;
   }
 #ifdef HFZ_EMU_SEC
   __shared__ uint16_t emu_sec[kF * (HFZ_EMU_BITS == 9 ? 1024 : 512)];
@@ -1964,6 +1970,19 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
     for (uint32_t i = tid; i < (HFZ_EMU_BITS == 9 ? 1024u : 512u); i += n_threads)
       emu_sec[pass * (HFZ_EMU_BITS == 9 ? 1024u : 512u) + i] = (uint16_t)(syms[i & 255] | (i << 8));
 #endif
+    if (kParts) {
+      // the first code's length is known for every prefix (l1tab): walk the window code by code
+      for (uint32_t r = tid; r < (1u << kMaxCodeLen); r += n_threads) {
+        uint32_t pos = 0, c = 0;
+        for (int it = 0; it < kMaxCodeLen; ++it) {
+          const uint32_t L = l1tab[(r >> pos) & ((1u << kDecTabBits) - 1)];
+          if (L == 0 || pos + L > (uint32_t)kMaxCodeLen) break;
+          pos += L;
+          ++c;
+        }
+        cntab[r] = (uint16_t)(pos | (c << 8));
+      }
+    }
     HFZ_BARRIER();  // table complete; the scratch aliased on the rings is free again
     STAMP(1);  // table
   }
@@ -2177,21 +2196,26 @@ __global__ __launch_bounds__(kParts ? 512 : 64 * kWaves) void decode_kernel(
             if (!__any(can)) break;
             if (can) {
               if (tgt - x > kDecRound * (uint32_t)kMaxCodeLen) {
-                // far from the target: a round of lookups as in the decoding loop, minus the output
+                // far from the target: a round of lookups as in the decoding loop, but in the
+                // counting table (all whole codes of a 12-bit window at once) and without output
                 const uint32_t ra_b = ra, sacc_b = sacc;
                 uint32_t cnt = 0;
+                const uint8_t* const cnb = (const uint8_t*)cntab;
+                constexpr uint32_t kCntMask = ((1u << kMaxCodeLen) - 1) << 1;
 #pragma unroll
                 for (uint32_t j = 0; j < kDecRound / 2; ++j) {
                   const uint64_t win = ((uint64_t)whi << 32) | wlo;
-                  const uint32_t e1 = HFZ_ENTRY((uint32_t)(win >> (sacc & 63)));
-                  sacc += e1;
-                  const uint32_t e2 = HFZ_ENTRY((uint32_t)(win >> (sacc & 63)));
+                  const uint32_t t1 = (uint32_t)(win >> (sacc & 63));
+                  const uint32_t e1 = *(const uint16_t*)(cnb + ((t1 >> 1) & kCntMask));
+                  sacc += e1;  // bits of the codes; what byte 1 adds lies above the bits looked at
+                  const uint32_t t2 = (uint32_t)(win >> (sacc & 63));
+                  const uint32_t e2 = *(const uint16_t*)(cnb + ((t2 >> 1) & kCntMask));
                   sacc += e2;
-                  cnt += (e1 & 0x1800u) + (e2 & 0x1800u);  // 8 * symbols sits in byte 1
+                  cnt += e1 + e2;  // byte 0 stays below 256 over a round (16 * 12 bits), so byte 1.. is the count
                   HFZ_REFILL();
                 }
                 x += ((ra - ra_b) >> 3) + sacc - sacc_b;  // 256 per dword = 8 per bit
-                n += cnt >> 11;
+                n += cnt >> 8;
               } else {
                 // near the target: an entry is taken whole while even its last bit lies
                 // before the target (then so does the boundary between its two codes);
@@ -2873,12 +2897,12 @@ int launch_decode(int K, const uint8_t* d_comp, uint64_t comp_bytes, const uint6
   for (;; --log2_parts) {
     threads = log2_parts ? (((uint32_t)K << log2_parts) + 63) & ~63u : 64u;
     ring_bytes = (size_t)(threads / 64) * 64 * (kDecInDw + kDecOutDw) * sizeof(uint32_t);
-    if (log2_parts == 0 || ring_bytes + (24u << 10) <= device_lds_per_block()) break;
+    if (log2_parts == 0 || ring_bytes + (32u << 10) <= device_lds_per_block()) break;  // 28.2 KiB of static LDS
   }
   if (log2_parts) {
 #define HFZ_LAUNCH_DECODE_PARTS(BITS, STORE)                                                      \
   do {                                                                                            \
-    if (ring_bytes > (40u << 10)) {                                                               \
+    if (ring_bytes > (32u << 10)) { /* beyond 64 KiB together with the static LDS */              \
       hipError_t e_ = hipFuncSetAttribute((const void*)&decode_kernel<BITS, 1, 1, STORE, true>,   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                           (int)ring_bytes);                                       \
