@@ -1,3 +1,5 @@
+"""Diagnostic: cycle stamps of the decoder on ONE frame (the several-threads-per-stream build),
+thread 0's wave (needs tools/libhfz_stamp.so, built with -DHFZ_STAMP).  Not part of the product."""
 import ctypes, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
