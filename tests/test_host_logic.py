@@ -45,6 +45,27 @@ def test_batch_frames():
     assert L.hfz_workspace_bytes(64, 10) >= 10 * (1024 + 792 + 256 + 4)
 
 
+def test_workspace_grows_only_for_batches_of_few_frames():
+    # 35 KiB per frame (histogram, code record, stream offsets, frame size, 32 KiB of
+    # counters) once one wavefront per frame fills the chip; below that, room on top for
+    # counting every stream in up to eight pieces (33 KiB per piece and frame + 2 KiB)
+    L = hfz.lib()
+
+    def up(x):
+        return (x + 255) & ~255
+
+    def base(n):
+        return up(n * 1024) + up(n * 792) + up(n * 256) + up(n * 4) + up(n * 32768)
+
+    for K, n in ((64, 2048), (64, 1024), (32, 2048), (1, 65536), (64, 100000)):
+        assert L.hfz_workspace_bytes(K, n) == base(n), (K, n)
+    for K, n, pieces in ((64, 1, 8), (64, 256, 4), (64, 512, 2), (32, 8, 8), (4, 11, 8), (16, 1024, 4)):
+        split = base(n) + up(n * pieces * 1024) + up(n * pieces * 32768) + up(n * 64 * 8 * 4)
+        assert L.hfz_workspace_bytes(K, n) == split, (K, n, L.hfz_workspace_bytes(K, n), split)
+    sizes = [L.hfz_workspace_bytes(64, n) for n in range(1, 3000, 7)]
+    assert all(s > 0 for s in sizes)
+
+
 def _same_table(hist):
     t = hfz.build_code_table(hist)
     c = oracle.make_coding(hist)
