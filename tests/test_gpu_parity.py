@@ -284,6 +284,28 @@ def test_other_stream_counts(torch_cuda):
         assert hfz.decompress(K, comp) == raw, K
 
 
+def test_every_stream_count(torch_cuda):
+    # every K the library accepts, single frames through the host-buffer calls and a
+    # small batch (ragged last frame) through the device entry points
+    torch = torch_cuda
+    raw = load_input("long_random.bin")[:20011]
+    total, frame = 3 * 7000 + 123, 7000
+    data = hfz.generate(geometric_cdf(), 5, total)
+    host = data.cpu().numpy().tobytes()
+    for K in range(1, 65):
+        comp = hfz.compress(K, raw)
+        assert comp == oracle.compress(K, raw), K
+        assert hfz.decompress(K, comp) == raw, K
+        codec = hfz.BatchCodec(K, total, frame)
+        batch = codec.compress(data)
+        out = codec.decompress(batch)
+        torch.cuda.synchronize()
+        assert int(codec.status.abs().sum().item()) == 0 and int(codec.dstatus.abs().sum().item()) == 0, K
+        assert torch.equal(out, data), K
+        for f in range(codec.n_frames):
+            assert batch.frame_bytes_host(f) == oracle.compress(K, host[f * frame:(f + 1) * frame]), (K, f)
+
+
 def test_compressor_concept(torch_cuda):
     c = hfz.HuffmanCompressorGpu(32)
     assert c.name() == "HuffmanGpu<32>"
