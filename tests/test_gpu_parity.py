@@ -326,6 +326,37 @@ def test_histogram(torch_cuda):
         assert np.array_equal(hfz.histogram(a), oracle.histogram(a)), (lo, n)
 
 
+@pytest.mark.skipif(not oracle.ref_available(),
+                    reason="oracle/_ref/libref_hist.so not built or this CPU lacks the AVX-512 subsets it uses")
+def test_histogram_against_the_compiled_reference(torch_cuda):
+    # the device histogram against huffman::MakeHistogram itself, compiled from the
+    # unmodified codec/histogram.cpp (oracle/Makefile, target `ref`): every fixture,
+    # the slice shapes CompressMulti<K> feeds it (codec/huffman.cpp:755-761), and the
+    # per-frame histograms of a batch
+    torch = torch_cuda
+    import os
+    from helpers import INPUTS
+    for name in sorted(f for f in os.listdir(INPUTS) if f.endswith(".bin")):
+        raw = load_input(name)
+        assert np.array_equal(hfz.histogram(raw), oracle.ref_histogram(raw)), name
+    big = np.frombuffer(load_input("long_random.bin"), dtype=np.uint8)
+    for lo, n in ((0, 1499), (1, 1500), (3, 1501), (5, 3125), (7, 3200), (9, 25600), (11, 65535), (13, 99987)):
+        part = big[lo:lo + n]
+        assert np.array_equal(hfz.histogram(part), oracle.ref_histogram(part)), (lo, n)
+    total, frame = 5 * 30000 + 777, 30000
+    data = hfz.generate(geometric_cdf(), 21, total)
+    host = data.cpu().numpy()
+    n_frames = (total + frame - 1) // frame
+    d_h = torch.zeros(n_frames * 256, dtype=torch.int32, device="cuda")
+    rc = hfz.lib().hfz_histogram_batch_dev(data.data_ptr(), total, frame, d_h.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = d_h.cpu().numpy().view(np.uint32).reshape(n_frames, 256)
+    for f in range(n_frames):
+        assert np.array_equal(got[f], oracle.ref_histogram(host[f * frame:(f + 1) * frame])), f
+
+
 # ---- generator --------------------------------------------------------------
 
 def test_generator_matches_oracle(torch_cuda):
