@@ -390,8 +390,8 @@ def main():
                                    "note": "independent batches taken in turn on two HIP streams; "
                                            "kernels of different batches share the chip, so no "
                                            "per-kernel times are quoted for it"}
-        except RuntimeError as e:  # e.g. no room for the second set of buffers: `value` stands
-            result["pipelined"] = {"error": str(e)[:200]}
+        except Exception as e:  # e.g. no room for the second set of buffers: `value` stands
+            result["pipelined"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     # Two more workloads beside the headline one, each a short run of its own after
     # it (one rank, default workload only): the 32-stream format on 1 GiB of
@@ -408,12 +408,15 @@ def main():
             try:
                 result[name] = side_measurement(hfz, dev, rank, steps=10, warmup=2,
                                                 time_every=args.time_every, **kw)
-            except RuntimeError as e:
-                result[name] = {"error": str(e)[:200]}
+            except Exception as e:  # the headline figures above stand whatever happens here
+                result[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         raw = host_raw
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(raw, total, K, frame_bytes, args.frame_kib)
+        try:
+            result["cpu_baseline"] = cpu_baseline(raw, total, K, frame_bytes, args.frame_kib)
+        except Exception as e:  # the GPU figures are not lost to a failing host-side leg
+            result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if _dist_on(world):
